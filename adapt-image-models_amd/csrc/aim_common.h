@@ -1,0 +1,97 @@
+// Shared device/host helpers for the AIM ViT-CLIP hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define AIM_LDS __attribute__((address_space(3)))
+#define AIM_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------
+void aim_set_error(const char* fmt, ...);
+#define AIM_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            aim_set_error(__VA_ARGS__);          \
+            return 1;                            \
+        }                                        \
+    } while (0)
+#define AIM_CHECK_LAUNCH(name)                                                    \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            aim_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16_t)a; r[1] = (bf16_t)b; r[2] = (bf16_t)c; r[3] = (bf16_t)d;
+    return r;
+}
+
+// QuickGELU x*sigmoid(1.702x) (reference vit_clip.py:80-82) and its derivative
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+// exact erf GELU (nn.GELU(), reference vit_clip.py:52) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// LDS image shared by every MFMA operand tile in this library: rows of 64 bf16 (128 B = eight
+// 16-byte chunks); chunk c of row r is stored at chunk position c ^ (r & 7).  Conflict-free for
+// the 16x16x32 operand ds_read_b128 (lane -> row l&15, chunk 4*ks + (l>>4)) and for
+// ds_read_b64_tr_b16 over 8 consecutive rows (derivation in DESIGN.md).
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + (((chunk ^ row) & 7) << 4); }
+
+// Stage `rows8 x 64` bf16 (8 rows of 128 B) into LDS with ONE buffer_load ... lds per wave:
+// lane l writes LDS bytes [16 l, 16 l + 16) of the 1 KiB piece, so it must fetch source chunk
+// (l & 7) ^ (l >> 3) of row (l >> 3) -- the swizzle goes on the SOURCE address.  Lanes whose row
+// or column is out of range pass an out-of-range voffset: the buffer bounds check returns 0 and
+// zero lands in LDS (zero-fill for ragged M / K tails).
+#define AIM_OOB 0x80000000u
+__device__ __forceinline__ void stage_piece(__amdgpu_buffer_rsrc_t rsrc, AIM_LDS char* lds_piece, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AIM_LDS void*)lds_piece, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
+    unsigned n = bytes > 0x7fffffffLL ? 0x7fffffffu : (bytes < 0 ? 0u : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+
+__device__ __forceinline__ bf16x8 lds_read8(const AIM_LDS char* p) { return *(const AIM_LDS bf16x8*)p; }
+__device__ __forceinline__ bf16x4 lds_read_tr4(const AIM_LDS char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AIM_LDS bf16x4*)p);
+}
+
+// XCD-aware bijective remap of a linear block id (8 XCDs, blocks dealt round-robin): blocks that
+// share an XCD get a contiguous range of logical ids (cdna guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}

@@ -1,0 +1,263 @@
+// Spatial multi-head self-attention backward (dQ, dK, dV), probabilities recomputed from the
+// forward's log-sum-exp.  gfx950 only.
+//
+// Autograd counterpart of reference vit_clip.py:139-156 (the reference relies on torch autograd
+// through bmm/softmax/bmm and keeps the [BT,H,N,N] probabilities alive for it).
+//
+// Two kernels per call, one workgroup (4 waves) per (frame, head) each:
+//   dq : query on the MFMA lane (same orientation as the forward).  Per 16-query tile and per pair
+//        of 16-key tiles:  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta) / 8 and
+//        dQ^T += K^T dS^T with the dS^T accumulators used directly as the MFMA's second operand
+//        (K^T fragments by ds_read_b64_tr_b16).  Also writes delta = rowsum(dO o O).
+//   dkv: key on the MFMA lane.  A wave owns 32 keys (K/V fragments in registers) and sweeps the
+//        queries 32 at a time:  S = Q K^T,  dP = dO V^T,  then  dV^T += dO^T P  and  dK^T += Q^T dS
+//        with P / dS accumulators as the second operand and Q^T / dO^T fragments by transposing
+//        reads of the row-major Q / dO images.  dK, dV need no cross-workgroup reduction.
+// Scores are recomputed twice (7 MFMA products instead of 5) in exchange for no dS exchange through
+// LDS and no atomics; attention is ~4 % of the block's FLOPs.
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N,
+                                                          int H, int nkt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
+    AIM_LDS char* sV = sK + nkt * 16 * 128;
+
+    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const bf16_t* base = qkv + (long long)bt * N * ld + h * 64;
+    {
+        __amdgpu_buffer_rsrc_t rK = make_rsrc(base + D, ((long long)(N - 1) * ld + 64) * 2);
+        __amdgpu_buffer_rsrc_t rV = make_rsrc(base + 2 * D, ((long long)(N - 1) * ld + 64) * 2);
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+        for (int p = wave; p < nkt * 2; p += 4) {
+            const int key = p * 8 + srow;
+            const unsigned voff = key < N ? (unsigned)((key * ld + schunk * 8) * 2) : AIM_OOB;
+            stage_piece(rK, sK + p * 1024, voff);
+            stage_piece(rV, sV + p * 1024, voff);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + frow;
+        const int qc = q < N ? q : N - 1;
+        bf16x8 qf[2], dof[2];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = (ks * 4 + fq) * 8;
+            qf[ks] = *(const bf16x8*)(base + (long long)qc * ld + c);
+            const long long orow = ((long long)bt * N + qc) * D + h * 64 + c;
+            dof[ks] = *(const bf16x8*)(dout + orow);
+            const bf16x8 of = *(const bf16x8*)(out + orow);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[e];
+        }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        const float L = lse[((long long)bt * H + h) * N + qc];
+        if (fq == 0 && q < N) delta[((long long)bt * H + h) * N + q] = dl;
+
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < nkt / 2; ++kk) {
+            bf16x8 dsf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * kk + u;
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kf = lds_read8(sK + swz_off(t * 16 + frow, ks * 4 + fq));
+                    const bf16x8 vf = lds_read8(sV + swz_off(t * 16 + frow, ks * 4 + fq));
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + fq * 4 + e;
+                    const float p = key < N ? __expf(s[e] * 0.125f - L) : 0.f;
+                    dsf[u * 4 + e] = (bf16_t)(p * (dp[e] - dl) * 0.125f);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int r0 = (2 * kk) * 16 + fq * 4 + (frow >> 2);
+                const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                const bf16x4 a = lds_read_tr4(sK + swz_off(r0, ch) + half);
+                const bf16x4 b = lds_read_tr4(sK + swz_off(r0 + 16, ch) + half);
+                bf16x8 ktf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ktf[e] = a[e];
+                    ktf[4 + e] = b[e];
+                }
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (q < N) {
+            bf16_t* op = dqkv + ((long long)bt * N + q) * ld + h * 64 + fq * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = pack4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int N, int H, int nq32) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AIM_LDS char* sQ = (AIM_LDS char*)smem_raw;
+    AIM_LDS char* sO = sQ + nq32 * 128;
+    AIM_LDS float* sL = (AIM_LDS float*)(sO + nq32 * 128);
+    AIM_LDS float* sD = sL + nq32;
+
+    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const bf16_t* base = qkv + (long long)bt * N * ld + h * 64;
+    const bf16_t* dob = dout + (long long)bt * N * D + h * 64;
+    {
+        __amdgpu_buffer_rsrc_t rQ = make_rsrc(base, ((long long)(N - 1) * ld + 64) * 2);
+        __amdgpu_buffer_rsrc_t rO = make_rsrc(dob, ((long long)(N - 1) * D + 64) * 2);
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+        for (int p = wave; p < nq32 / 8; p += 4) {
+            const int qr = p * 8 + srow;
+            stage_piece(rQ, sQ + p * 1024, qr < N ? (unsigned)((qr * ld + schunk * 8) * 2) : AIM_OOB);
+            stage_piece(rO, sO + p * 1024, qr < N ? (unsigned)((qr * D + schunk * 8) * 2) : AIM_OOB);
+        }
+        for (int i = tid; i < nq32; i += 256) {
+            sL[i] = i < N ? lse[((long long)bt * H + h) * N + i] : 0.f;
+            sD[i] = i < N ? delta[((long long)bt * H + h) * N + i] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkp = (N + 31) >> 5;
+    for (int kp = wave; kp < nkp; kp += 4) {
+        bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key = kp * 32 + u * 16 + frow;
+            const int kc = key < N ? key : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[u][ks] = *(const bf16x8*)(base + (long long)kc * ld + D + (ks * 4 + fq) * 8);
+                vf[u][ks] = *(const bf16x8*)(base + (long long)kc * ld + 2 * D + (ks * 4 + fq) * 8);
+            }
+        }
+        f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dk[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dv[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        for (int qs = 0; qs < nq32 / 32; ++qs) {
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {  // the two 16-query tiles of this step
+                const int qrow = (2 * qs + w) * 16;
+                bf16x8 qa[2], oa[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    qa[ks] = lds_read8(sQ + swz_off(qrow + frow, ks * 4 + fq));
+                    oa[ks] = lds_read8(sO + swz_off(qrow + frow, ks * 4 + fq));
+                }
+                float Lr[4], Dr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Lr[e] = sL[qrow + fq * 4 + e];
+                    Dr[e] = sD[qrow + fq * 4 + e];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[u][ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[ks], vf[u][ks], dp, 0, 0, 0);
+                    }
+                    const bool kin = (kp * 32 + u * 16 + frow) < N;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = kin ? __expf(s[e] * 0.125f - Lr[e]) : 0.f;
+                        pf[u][w * 4 + e] = (bf16_t)p;
+                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - Dr[e]) * 0.125f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int r0 = qs * 32 + fq * 4 + (frow >> 2);
+                const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                bf16x8 qt8, ot8;
+                {
+                    const bf16x4 a = lds_read_tr4(sQ + swz_off(r0, ch) + half);
+                    const bf16x4 b = lds_read_tr4(sQ + swz_off(r0 + 16, ch) + half);
+                    const bf16x4 c = lds_read_tr4(sO + swz_off(r0, ch) + half);
+                    const bf16x4 d = lds_read_tr4(sO + swz_off(r0 + 16, ch) + half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        qt8[e] = a[e];
+                        qt8[4 + e] = b[e];
+                        ot8[e] = c[e];
+                        ot8[4 + e] = d[e];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    dv[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot8, pf[u], dv[dt][u], 0, 0, 0);
+                    dk[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsf[u], dk[dt][u], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key = kp * 32 + u * 16 + frow;
+            if (key < N) {
+                bf16_t* op = dqkv + ((long long)bt * N + key) * ld + h * 64 + fq * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *(bf16x4*)(op + D + dt * 16) = pack4(dk[dt][u][0], dk[dt][u][1], dk[dt][u][2], dk[dt][u][3]);
+                    *(bf16x4*)(op + 2 * D + dt * 16) = pack4(dv[dt][u][0], dv[dt][u][1], dv[dt][u][2], dv[dt][u][3]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// workspace-free: delta is written into the caller-provided `delta` buffer ([BT, H, N] f32)
+extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_bf16* dout, const float* lse,
+                            float* delta, aim_bf16* dqkv, int BT, int N, int H, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 0 && H > 0 && N <= 288, "attn_bwd: unsupported shape BT=%d N=%d H=%d (N <= 288)", BT, N, H);
+    AIM_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nkt = ((N + 31) / 32) * 2;   // 16-key tiles, even
+    const int nq32 = ((N + 31) / 32) * 32;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(BT * H), dim3(256), nkt * 16 * 128 * 2, st, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, nkt);
+    AIM_CHECK_LAUNCH("aim_attn_bwd(dq)");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(BT * H), dim3(256), nq32 * 128 * 2 + nq32 * 8, st, (const bf16_t*)qkv,
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, nq32);
+    AIM_CHECK_LAUNCH("aim_attn_bwd(dkv)");
+    return 0;
+}

@@ -1,0 +1,146 @@
+// Spatial multi-head self-attention forward over the N tokens of one frame.  gfx950 only.
+//
+// Replaces reference vit_clip.py:139-156 (view/permute to [Nb,H,S,dh], q@k^T / sqrt(dh), softmax,
+// @v, merge heads) for the spatial call at :264.  The [BT,H,N,N] score tensor the reference
+// materialises (0.95 GB fp32 per layer at config 2) never leaves the CU.
+//
+// One workgroup (4 waves) per (frame, head).  K and V of that head (N <= 288 keys x 64) are staged
+// once into swizzled LDS images by buffer_load...lds (zero-filled past N).  Each wave takes 16-row
+// query tiles round-robin:  S^T = K Q^T with the KEY on the MFMA row and the QUERY on the lane, so a
+// query's whole score row sits in one lane quartet (2 shuffles per reduction) and the normalised
+// P^T accumulators are, unchanged, the second operand of  O^T = V^T P^T  (V^T fragments come from
+// the row-major V image through ds_read_b64_tr_b16).  O^T puts 4 consecutive head-dim elements of a
+// query in one lane: 8-byte stores into the merged-heads [M, D] layout.
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+namespace {
+
+template <int NKT>  // number of 16-key tiles (even)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
+    AIM_LDS char* sV = sK + NKT * 16 * 128;
+
+    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+
+    const bf16_t* base = qkv + (long long)bt * N * ld + h * 64;
+    {
+        __amdgpu_buffer_rsrc_t rK = make_rsrc(base + D, ((long long)(N - 1) * ld + 64) * 2);
+        __amdgpu_buffer_rsrc_t rV = make_rsrc(base + 2 * D, ((long long)(N - 1) * ld + 64) * 2);
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+        for (int p = wave; p < NKT * 2; p += 4) {
+            const int key = p * 8 + srow;
+            const unsigned voff = key < N ? (unsigned)((key * ld + schunk * 8) * 2) : AIM_OOB;
+            stage_piece(rK, sK + p * 1024, voff);
+            stage_piece(rV, sV + p * 1024, voff);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + frow;
+        const int qc = q < N ? q : N - 1;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qc * ld + (ks * 4 + fq) * 8);
+
+        f32x4 s[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = lds_read8(sK + swz_off(t * 16 + frow, ks * 4 + fq));
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+        // softmax over keys: lane holds keys t*16 + fq*4 + e for query (lane & 15)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = t * 16 + fq * 4 + e;
+                const float v = key < N ? s[t][e] * 0.125f : -INFINITY;
+                s[t][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __expf(s[t][e] - mx);
+                s[t][e] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx + __logf(sum);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NKT / 2; ++kk) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[e] = (bf16_t)(s[2 * kk][e] * inv);
+                pf[4 + e] = (bf16_t)(s[2 * kk + 1][e] * inv);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                // V^T fragment: rows key0 + (i>>2), columns dt*16 + 4*(i&3) .. +3 of the V image (i = lane&15)
+                const int r0 = (2 * kk) * 16 + fq * 4 + (frow >> 2);
+                const int r1 = r0 + 16;
+                const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                const bf16x4 v0 = lds_read_tr4(sV + swz_off(r0, ch) + half);
+                const bf16x4 v1 = lds_read_tr4(sV + swz_off(r1, ch) + half);
+                bf16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vf[e] = v0[e];
+                    vf[4 + e] = v1[e];
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < N) {
+            bf16_t* op = out + ((long long)bt * N + q) * D + h * 64 + fq * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        }
+    }
+}
+
+template <int NKT>
+int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
+    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(BT * H), dim3(256), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
+                       (bf16_t*)out, lse, N, H);
+    AIM_CHECK_LAUNCH("aim_attn_fwd");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int aim_attn_fwd(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 0 && H > 0 && N <= 288, "attn_fwd: unsupported shape BT=%d N=%d H=%d (N <= 288)", BT, N, H);
+    AIM_CHECK_ARG(qkv && out && lse, "attn_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 32) return launch<2>(qkv, out, lse, BT, N, H, st);
+    if (N <= 64) return launch<4>(qkv, out, lse, BT, N, H, st);
+    if (N <= 224) return launch<14>(qkv, out, lse, BT, N, H, st);
+    return launch<18>(qkv, out, lse, BT, N, H, st);
+}

@@ -1,0 +1,192 @@
+// Temporal attention over the T class tokens of each clip, and the per-frame lamda statistic.
+// gfx950 only.
+//
+// cls_attn_*: reference vit_clip.py:220-224 -- attention() (:139-156) applied to
+//   rearrange(x[:1], 'n (b t) d -> t (b n) d'), i.e. sequence = the T class tokens of a clip,
+//   batch = B.  Sequence length is T <= 32, so this is a latency-bound scalar kernel: one wave per
+//   (clip, head), lane = head-dim element, everything in LDS.  The q/k/v rows are the class rows
+//   (token 0) of the frame-major fused qkv buffer (same in_proj weights, same ln_1 rows).
+// lambda: reference vit_clip.py:149-151,184-186,272 -- lamda = cw / (cw + ow) with
+//   ow = sum_{i,j} exp(sum_h aff_h[i,j]) = sum exp(q_i . k_j / sqrt(dh)) over the full width D and
+//   cw = sum_i exp(q_i . kx / sqrt(dh)).  ow arrives as (max, sum) partials of the EXPSUM GEMM;
+//   cw is computed here; one shared max shift keeps the ratio exact without fp32 overflow.
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+namespace {
+
+constexpr int TMAX = 32;
+
+__global__ __launch_bounds__(64) void cls_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ probs, int T, int N, int H) {
+    __shared__ float sq[TMAX][65], sk[TMAX][65], sv[TMAX][65], sp[TMAX][TMAX + 1];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64, ld = 3 * D, lane = threadIdx.x;
+    for (int t = 0; t < T; ++t) {
+        const bf16_t* r = qkv + ((long long)(b * T + t) * N) * ld + h * 64 + lane;
+        sq[t][lane] = (float)r[0];
+        sk[t][lane] = (float)r[D];
+        sv[t][lane] = (float)r[2 * D];
+    }
+    __syncthreads();
+    for (int p = lane; p < T * T; p += 64) {
+        const int tq = p / T, tk = p - tq * T;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) acc += sq[tq][d] * sk[tk][d];
+        sp[tq][tk] = acc * 0.125f;
+    }
+    __syncthreads();
+    for (int tq = lane; tq < T; tq += 64) {
+        float mx = -INFINITY;
+        for (int tk = 0; tk < T; ++tk) mx = fmaxf(mx, sp[tq][tk]);
+        float sum = 0.f;
+        for (int tk = 0; tk < T; ++tk) {
+            const float e = expf(sp[tq][tk] - mx);
+            sp[tq][tk] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int tk = 0; tk < T; ++tk) {
+            const float p = sp[tq][tk] * inv;
+            sp[tq][tk] = p;
+            probs[(((long long)b * H + h) * T + tq) * T + tk] = p;
+        }
+    }
+    __syncthreads();
+    for (int tq = 0; tq < T; ++tq) {
+        float acc = 0.f;
+        for (int tk = 0; tk < T; ++tk) acc += sp[tq][tk] * sv[tk][lane];
+        out[(long long)(b * T + tq) * D + h * 64 + lane] = (bf16_t)acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void cls_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ probs,
+                                                          const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                          int T, int N, int H) {
+    __shared__ float sq[TMAX][65], sk[TMAX][65], sv[TMAX][65], sdo[TMAX][65], sp[TMAX][TMAX + 1], sds[TMAX][TMAX + 1];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64, ld = 3 * D, lane = threadIdx.x;
+    for (int t = 0; t < T; ++t) {
+        const bf16_t* r = qkv + ((long long)(b * T + t) * N) * ld + h * 64 + lane;
+        sq[t][lane] = (float)r[0];
+        sk[t][lane] = (float)r[D];
+        sv[t][lane] = (float)r[2 * D];
+        sdo[t][lane] = (float)dout[(long long)(b * T + t) * D + h * 64 + lane];
+    }
+    for (int p = lane; p < T * T; p += 64) {
+        const int tq = p / T, tk = p - tq * T;
+        sp[tq][tk] = probs[(((long long)b * H + h) * T + tq) * T + tk];
+    }
+    __syncthreads();
+    // dP[tq][tk] = dO[tq] . V[tk]
+    for (int p = lane; p < T * T; p += 64) {
+        const int tq = p / T, tk = p - tq * T;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) acc += sdo[tq][d] * sv[tk][d];
+        sds[tq][tk] = acc;
+    }
+    __syncthreads();
+    for (int tq = lane; tq < T; tq += 64) {
+        float dot = 0.f;
+        for (int tk = 0; tk < T; ++tk) dot += sp[tq][tk] * sds[tq][tk];
+        for (int tk = 0; tk < T; ++tk) sds[tq][tk] = sp[tq][tk] * (sds[tq][tk] - dot) * 0.125f;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int u = 0; u < T; ++u) {
+            dq += sds[t][u] * sk[u][lane];
+            dk += sds[u][t] * sq[u][lane];
+            dv += sp[u][t] * sdo[u][lane];
+        }
+        bf16_t* r = dqkv + ((long long)(b * T + t) * N) * ld + h * 64 + lane;
+        r[0] = (bf16_t)((float)r[0] + dq);
+        r[D] = (bf16_t)((float)r[D] + dk);
+        r[2 * D] = (bf16_t)((float)r[2 * D] + dv);
+    }
+}
+
+// one block (4 waves) per frame
+__global__ __launch_bounds__(256) void lambda_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx,
+                                                     const float* __restrict__ partials, int ntiles,
+                                                     float* __restrict__ lam, float* __restrict__ oml, int N, int D,
+                                                     float scale) {
+    __shared__ float ss[320];
+    __shared__ float red[8];
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = 3 * D;
+    const bf16_t* kr = kx + (long long)bt * D;
+    for (int i = wave; i < N; i += 4) {
+        const bf16_t* qr = qkv + ((long long)bt * N + i) * ld;
+        float acc = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const bf16x4 a = *(const bf16x4*)(qr + c);
+            const bf16x4 b = *(const bf16x4*)(kr + c);
+            acc += (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1] + (float)a[2] * (float)b[2] + (float)a[3] * (float)b[3];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) ss[i] = acc * scale;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, ss[i]);
+    for (int t = tid; t < ntiles; t += 256) mx = fmaxf(mx, partials[((long long)bt * ntiles + t) * 2]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float cw = 0.f, ow = 0.f;
+    for (int i = tid; i < N; i += 256) cw += expf(ss[i] - mx);
+    for (int t = tid; t < ntiles; t += 256) {
+        const float* p = partials + ((long long)bt * ntiles + t) * 2;
+        if (p[0] > -INFINITY) ow += p[1] * expf(p[0] - mx);
+    }
+    cw = wave_sum(cw);
+    ow = wave_sum(ow);
+    __syncthreads();
+    if (lane == 0) {
+        red[wave] = cw;
+        red[4 + wave] = ow;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float c = red[0] + red[1] + red[2] + red[3], o = red[4] + red[5] + red[6] + red[7];
+        const float l = c / (c + o);
+        lam[bt] = l;
+        if (oml) oml[bt] = 1.0f - l;
+    }
+}
+
+}  // namespace
+
+extern "C" int aim_cls_attn_fwd(const aim_bf16* qkv, aim_bf16* out_cls, float* probs, int B, int T, int N, int H,
+                                void* stream) {
+    AIM_CHECK_ARG(B > 0 && T > 0 && T <= TMAX && N > 0 && H > 0, "cls_attn_fwd: unsupported shape B=%d T=%d (T <= 32)", B, T);
+    AIM_CHECK_ARG(qkv && out_cls && probs, "cls_attn_fwd: null pointer");
+    hipLaunchKernelGGL(cls_attn_fwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (bf16_t*)out_cls, probs, T, N, H);
+    AIM_CHECK_LAUNCH("aim_cls_attn_fwd");
+    return 0;
+}
+
+extern "C" int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout_cls, aim_bf16* dqkv,
+                                int B, int T, int N, int H, void* stream) {
+    AIM_CHECK_ARG(B > 0 && T > 0 && T <= TMAX && N > 0 && H > 0, "cls_attn_bwd: unsupported shape B=%d T=%d (T <= 32)", B, T);
+    AIM_CHECK_ARG(qkv && probs && dout_cls && dqkv, "cls_attn_bwd: null pointer");
+    hipLaunchKernelGGL(cls_attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qkv, probs,
+                       (const bf16_t*)dout_cls, (bf16_t*)dqkv, T, N, H);
+    AIM_CHECK_LAUNCH("aim_cls_attn_bwd");
+    return 0;
+}
+
+extern "C" int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, const float* partials, int ntiles, float* lam,
+                          float* one_minus_lam, int BT, int N, int D, float scale, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 0 && N <= 320 && D > 0 && (D % 4) == 0, "lambda: unsupported shape BT=%d N=%d D=%d", BT, N, D);
+    AIM_CHECK_ARG(qkv && kx && partials && lam && ntiles > 0, "lambda: null pointer");
+    hipLaunchKernelGGL(lambda_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
+                       (const bf16_t*)kx, partials, ntiles, lam, one_minus_lam, N, D, scale);
+    AIM_CHECK_LAUNCH("aim_lambda");
+    return 0;
+}

@@ -1,0 +1,324 @@
+// Patch-embedding glue and the small reductions / casts around the AIM block.  gfx950 only.
+//
+// patchify / embed_ln / embed_bwd: reference vit_clip.py:434-447 -- rearrange 'b c t h w -> (b t) c h w',
+//   conv1 (kernel = stride = patch, no bias; done as a GEMM over the patch matrix written here),
+//   class_embedding concat (:439), + positional_embedding (:440), + temporal_embedding (:443-445),
+//   ln_pre (:447).  Optional uint8 input fuses the GPUNormalize pre-hook
+//   (mmaction/utils/module_hooks.py:73-85): x.float().sub_(mean).div_(std).
+// frame_sum / colsum / cast / scale_rows: bandwidth-bound helpers for the hand-written backward
+//   (per-frame token sums for the broadcast S_Adapter term, bias gradients, bf16 weight staging).
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+namespace {
+
+constexpr int MAXC = 8;
+
+// A[(bt*G*G + gy*G + gx)][c*p*p + py*p + px] = img[b][c][t][gy*p+py][gx*p+px]; one thread per 8 columns
+template <typename TIN>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ img, const float* __restrict__ mean3,
+                                                       const float* __restrict__ std3, bf16_t* __restrict__ A, int B,
+                                                       int T, int H, int W, int p, int Kp) {
+    const int G = W / p, Gy = H / p, K = 3 * p * p;
+    const long long rows = (long long)B * T * Gy * G;
+    const int cpr = Kp / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cpr) return;
+    const long long row = idx / cpr;
+    const int k0 = (int)(idx - row * cpr) * 8;
+    const int gx = (int)(row % G), gy = (int)((row / G) % Gy);
+    const long long bt = row / ((long long)G * Gy);
+    const int t = (int)(bt % T);
+    const long long b = bt / T;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
+            const long long src = (((b * 3 + c) * T + t) * H + (gy * p + py)) * (long long)W + gx * p + px;
+            v = (float)img[src];
+            if (mean3) v = (v - mean3[c]) / std3[c];
+        }
+        o[e] = (bf16_t)v;
+    }
+    *(bf16x8*)(A + row * Kp + k0) = o;
+}
+
+__device__ __forceinline__ f32x4 embed_value(const bf16_t* tok, const float* cls, const float* pos, const float* tmp,
+                                             long long bt, int n, int t, int G2, int D, int c4) {
+    f32x4 v;
+    if (n == 0) {
+        v = *(const f32x4*)(cls + c4);
+    } else {
+        const bf16x4 tk = *(const bf16x4*)(tok + (bt * G2 + (n - 1)) * D + c4);
+        v = f32x4{(float)tk[0], (float)tk[1], (float)tk[2], (float)tk[3]};
+    }
+    v += *(const f32x4*)(pos + (long long)n * D + c4);
+    v += *(const f32x4*)(tmp + (long long)t * D + c4);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict__ tok, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, const float* __restrict__ tmp,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ x, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int B, int T, int N, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * T * N) return;
+    const long long bt = row / N;
+    const int n = (int)(row - bt * N), t = (int)(bt % T), nch = D >> 2;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            v[c] = embed_value(tok, cls, pos, tmp, bt, n, t, N - 1, D, ch * 4);
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+            *(f32x4*)(x + row * D + ch * 4) = y;
+        }
+    }
+}
+
+// grid (T, chunks): every wave walks rows (b, n) of frame-time t, accumulates ln_pre's input gradient
+// in registers and adds it into dtemporal[t] once at the end.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ tok,
+                                                        const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        const float* __restrict__ tmp, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        float* __restrict__ dtemporal, int B, int T, int N, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x, nch = D >> 2;
+    f32x4 acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int total = B * N;
+    for (int r = blockIdx.y * 4 + wave; r < total; r += gridDim.y * 4) {
+        const int b = r / N, n = r - b * N;
+        const long long bt = (long long)b * T + t, row = bt * N + n;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[MAXC], xh[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                const f32x4 v = embed_value(tok, cls, pos, tmp, bt, n, t, N - 1, D, ch * 4);
+                const f32x4 d = *(const f32x4*)(dx + row * D + ch * 4);
+                const f32x4 gm = *(const f32x4*)(gamma + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[c][e] = (v[e] - mu) * rs;
+                    g[c][e] = d[e] * gm[e];
+                    s1 += g[c][e];
+                    s2 += g[c][e] * xh[c][e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] += rs * (g[c][e] - m1 - xh[c][e] * m2);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dtemporal + (long long)t * D + ch * 4 + e, acc[c][e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void frame_sum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ out, int ntok, int D) {
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    if (d >= D) return;
+    const long long f = blockIdx.x;
+    const float* p = x + f * ntok * (long long)D + d;
+    float acc = 0.f;
+    for (int t = 0; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * p[(long long)t * D];
+    out[f * D + d] = acc;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ af,
+                                                     const float* __restrict__ at, int ntok, float* __restrict__ out,
+                                                     int M, int C, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float rs = 1.f;
+        if (af || at) {
+            const int f = r / ntok, tk = r - f * ntok;
+            if (af) rs *= af[f];
+            if (at) rs *= at[tk];
+        }
+        acc += rs * (float)X[(long long)r * ldx + c];
+    }
+    atomicAdd(out + c, acc);
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *(const f32x4*)(src + i);
+        *(bf16x4*)(dst + i) = pack4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (long long j = i; j < n; ++j) dst[j] = (bf16_t)src[j];
+    }
+}
+
+// dst[c][r] = src[r][c]
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(long long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(long long)c * R + r] = (bf16_t)tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                         bf16_t* __restrict__ y, float* __restrict__ yf, int R, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R * C) return;
+    const float v = x[i] * s[i / C];
+    if (y) y[i] = (bf16_t)v;
+    if (yf) yf[i] = v;
+}
+
+}  // namespace
+
+extern "C" int aim_patchify(const void* imgs, int in_dtype, const float* mean3, const float* std3, aim_bf16* A, int B,
+                            int T, int H, int W, int p, int Kp, void* stream) {
+    AIM_CHECK_ARG(B > 0 && T > 0 && p > 0 && H % p == 0 && W % p == 0, "patchify: bad shape H=%d W=%d p=%d", H, W, p);
+    AIM_CHECK_ARG(Kp >= 3 * p * p && (Kp % 8) == 0, "patchify: Kp=%d must be >= 3*p*p and a multiple of 8", Kp);
+    AIM_CHECK_ARG(imgs && A && ((!mean3) == (!std3)), "patchify: null pointer");
+    const long long total = (long long)B * T * (H / p) * (W / p) * (Kp / 8);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == 0)
+        hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, st, (const float*)imgs, mean3, std3, (bf16_t*)A, B, T, H, W, p, Kp);
+    else if (in_dtype == 1)
+        hipLaunchKernelGGL(patchify_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)imgs, mean3, std3, (bf16_t*)A, B, T, H, W, p, Kp);
+    else if (in_dtype == 2)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)imgs, mean3, std3, (bf16_t*)A, B, T, H, W, p, Kp);
+    else {
+        aim_set_error("patchify: in_dtype must be 0 (f32), 1 (uint8) or 2 (bf16), got %d", in_dtype);
+        return 1;
+    }
+    AIM_CHECK_LAUNCH("aim_patchify");
+    return 0;
+}
+
+extern "C" int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* pos, const float* temporal,
+                            const float* gamma, const float* beta, float* x, float* mean, float* rstd, int B, int T,
+                            int N, int D, float eps, void* stream) {
+    AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_ln: bad shape N=%d D=%d", N, D);
+    AIM_CHECK_ARG(tok && cls && pos && temporal && gamma && beta && x && mean && rstd, "embed_ln: null pointer");
+    const long long rows = (long long)B * T * N;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)tok, cls, pos, temporal, gamma, beta, x, mean, rstd, B, T, N, D, eps);
+    AIM_CHECK_LAUNCH("aim_embed_ln");
+    return 0;
+}
+
+extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const float* pos,
+                             const float* temporal, const float* gamma, const float* mean, const float* rstd,
+                             float* dtemporal, int B, int T, int N, int D, void* stream) {
+    AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_bwd: bad shape N=%d D=%d", N, D);
+    AIM_CHECK_ARG(dx && tok && cls && pos && temporal && gamma && mean && rstd && dtemporal, "embed_bwd: null pointer");
+    int chunks = (B * N + 3) / 4;
+    if (chunks > 128) chunks = 128;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, chunks), dim3(256), 0, (hipStream_t)stream, dx, (const bf16_t*)tok, cls,
+                       pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D);
+    AIM_CHECK_LAUNCH("aim_embed_bwd");
+    return 0;
+}
+
+extern "C" int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream) {
+    AIM_CHECK_ARG(frames > 0 && ntok > 0 && D > 0 && x && out, "frame_sum: bad arguments");
+    hipLaunchKernelGGL(frame_sum_kernel, dim3(frames, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, out, ntok, D);
+    AIM_CHECK_LAUNCH("aim_frame_sum");
+    return 0;
+}
+
+extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok, float* out,
+                               int M, int C, void* stream) {
+    AIM_CHECK_ARG(M > 0 && C > 0 && X && out, "colsum: bad arguments");
+    if (af || at) AIM_CHECK_ARG(ntok > 0, "colsum: ntok required with row factors");
+    int rpb = (M + 511) / 512;
+    if (rpb < 64) rpb = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X, ldx, af, at, ntok, out, M, C, rpb);
+    AIM_CHECK_LAUNCH("aim_colsum_bf16");
+    return 0;
+}
+
+extern "C" int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, void* stream) {
+    AIM_CHECK_ARG(R > 0 && C > 0 && src && dst, "cast: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (transpose) {
+        hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, (bf16_t*)dst, R, C);
+    } else {
+        const long long n = (long long)R * C;
+        hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    }
+    AIM_CHECK_LAUNCH("aim_cast_bf16");
+    return 0;
+}
+
+extern "C" int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream) {
+    AIM_CHECK_ARG(R > 0 && C > 0 && x && s && (y || y_f32), "scale_rows: bad arguments");
+    const long long n = (long long)R * C;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, s,
+                       (bf16_t*)y, y_f32, R, C);
+    AIM_CHECK_LAUNCH("aim_scale_rows");
+    return 0;
+}

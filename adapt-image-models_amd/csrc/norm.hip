@@ -1,0 +1,151 @@
+// LayerNorm forward / backward (fp32 statistics) for the AIM block.  gfx950 only.
+//
+// Replaces reference vit_clip.py:71-77 (`LayerNorm.forward`: fp32 nn.LayerNorm, eps 1e-5) at its
+// call sites ln_1 (:224,264,265), ln_2 (:285), ln_pre (:447), ln_post (:452).
+// One 64-lane wave per row, 4 rows per 256-thread block; the row lives in registers (float4 chunks),
+// two-pass mean / variance, wavefront shuffles for the reductions; HBM-bound by design:
+// fwd moves 4 B (x) + 2 B (bf16 y) per element.
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // float4 chunks per lane: D <= 8*4*64 = 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16_t* __restrict__ yb, float* __restrict__ yf, long long ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 2;
+    const float* xr = x + (long long)row * ldx;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            v[c] = *(const f32x4*)(xr + ch * 4);
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+            const f32x4 b = *(const f32x4*)(beta + ch * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+            if (yb) *(bf16x4*)(yb + (long long)row * ldy + ch * 4) = pack4(y[0], y[1], y[2], y[3]);
+            if (yf) *(f32x4*)(yf + (long long)row * ldy + ch * 4) = y;
+        }
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long long lddy,
+                                                     const float* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, bf16_t* __restrict__ dxb, long long lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 2;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 g[MAXC], xh[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            const f32x4 d = *(const f32x4*)(dy + (long long)row * lddy + ch * 4);
+            const f32x4 xv = *(const f32x4*)(x + (long long)row * ldx + ch * 4);
+            const f32x4 gm = *(const f32x4*)(gamma + ch * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[c][e] = (xv[e] - mu) * rs;
+                g[c][e] = d[e] * gm[e];
+                s1 += g[c][e];
+                s2 += g[c][e] * xh[c][e];
+            }
+            if (dgamma) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(dgamma + ch * 4 + e, d[e] * xh[c][e]);
+                    atomicAdd(dbeta + ch * 4 + e, d[e]);
+                }
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (g[c][e] - m1 - xh[c][e] * m2);
+            if (dres) {
+                const f32x4 r = *(const f32x4*)(dres + (long long)row * lddx + ch * 4);
+                o += r;
+            }
+            if (dx) *(f32x4*)(dx + (long long)row * lddx + ch * 4) = o;
+            if (dxb) *(bf16x4*)(dxb + (long long)row * lddx + ch * 4) = pack4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                 aim_bf16* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
+                                 int rows, int D, float eps, void* stream) {
+    AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_fwd: bad shape rows=%d D=%d", rows, D);
+    AIM_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
+    AIM_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "layernorm_fwd: strides must be multiples of 4");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma,
+                       beta, (bf16_t*)y_bf16, y_f32, (long long)ldy, mean, rstd, rows, D, eps);
+    AIM_CHECK_LAUNCH("aim_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, const float* dres, float* dx,
+                                 aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int rows, int D,
+                                 void* stream) {
+    AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_bwd: bad shape rows=%d D=%d", rows, D);
+    AIM_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "layernorm_bwd: null pointer");
+    AIM_CHECK_ARG((!dgamma) == (!dbeta), "layernorm_bwd: dgamma and dbeta go together");
+    AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (long long)lddy, x,
+                       (long long)ldx, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta,
+                       rows, D);
+    AIM_CHECK_LAUNCH("aim_layernorm_bwd");
+    return 0;
+}

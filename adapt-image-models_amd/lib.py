@@ -1,0 +1,88 @@
+"""ctypes binding of libaim_hip.so (C ABI: include/aim_kernels.h)."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libaim_hip.so")
+
+
+class GemmArgs(Structure):
+    """Mirror of ``aim_gemm_args``."""
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("lda", c_int32), ("ldw", c_int32),
+        ("strideA", c_int64), ("strideW", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("bias", c_void_p), ("resid", c_void_p), ("ldr", c_int32),
+        ("af", c_void_p), ("at", c_void_p), ("vec", c_void_p), ("bt", c_void_p),
+        ("ldv", c_int32), ("ntok", c_int32),
+        ("aux", c_void_p), ("ldaux", c_int32),
+        ("out", c_void_p), ("ldo", c_int32), ("out2", c_void_p), ("ldo2", c_int32),
+        ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32),
+    ]
+
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+# name -> argtypes; every entry point include/aim_kernels.h declares
+SIGNATURES = {
+    "aim_version": [],
+    "aim_last_error": [],
+    "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
+    "aim_gemm_expsum_tiles": [I, I],
+    "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P],
+    "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
+    "aim_layernorm_bwd": [P, L, P, L, P, P, P, P, P, P, L, P, P, I, I, P],
+    "aim_attn_fwd": [P, P, P, I, I, I, P],
+    "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
+    "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
+    "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, P],
+    "aim_lambda": [P, P, P, I, P, P, I, I, I, F, P],
+    "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],
+    "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "aim_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "aim_frame_sum": [P, P, P, I, I, I, P],
+    "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P],
+    "aim_cast_bf16": [P, P, I, I, I, P],
+    "aim_scale_rows": [P, P, P, P, I, I, P],
+}
+
+ABI_VERSION = 1
+
+
+def load_library():
+    """Load libaim_hip.so once; raise ``LibraryNotBuilt`` (never fall back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LibraryNotBuilt(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C adapt-image-models_amd/csrc`). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "aim_last_error" else c_int
+    if lib.aim_version() != ABI_VERSION:
+        raise LibraryNotBuilt(f"{path}: ABI version {lib.aim_version()} != {ABI_VERSION}; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load_library().aim_last_error()
+        raise RuntimeError(f"libaim_hip {what} failed (rc={rc}): {msg.decode() if msg else '?'}")

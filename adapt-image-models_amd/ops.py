@@ -1,0 +1,199 @@
+"""Thin tensor-level wrappers over the C ABI (include/aim_kernels.h).
+
+PyTorch is used for device memory and streams only; every function here launches exactly the HIP
+kernel(s) of the same name on the current stream and returns without synchronising.
+"""
+from ctypes import byref
+from typing import Optional
+
+import torch
+
+from .lib import GemmArgs, check, load_library
+
+EPI_BF16, EPI_ACT, EPI_DACT, EPI_F32, EPI_EXPSUM = 0, 1, 2, 3, 4
+ACT_QGELU, ACT_GELU = 0, 1
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=None, resid=None,
+         af=None, at=None, vec=None, bt=None, ntok: int = 0, aux=None, out2=None, act: int = 0,
+         scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
+         stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
+         lda: Optional[int] = None, ldw: Optional[int] = None):
+    """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
+    lib = load_library()
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    for n_, t_ in (("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
+        _chk(t_, F32, n_)
+    _chk(aux, BF16, "aux"); _chk(out2, BF16, "out2")
+    g = GemmArgs()
+    g.A, g.W = a.data_ptr(), w.data_ptr()
+    g.M = a.shape[0] if M is None else M
+    g.K = a.shape[1] if K is None else K
+    g.N = w.shape[0] if N is None else N
+    g.lda = a.stride(0) if lda is None else lda
+    g.ldw = w.stride(0) if ldw is None else ldw
+    g.strideA, g.strideW = stride_a, stride_w
+    g.bias, g.resid = _p(bias), _p(resid)
+    g.ldr = resid.stride(0) if resid is not None else 0
+    g.af, g.at, g.vec, g.bt = _p(af), _p(at), _p(vec), _p(bt)
+    g.ldv = vec.stride(0) if vec is not None else 0
+    g.ntok = ntok
+    g.aux = _p(aux)
+    g.ldaux = aux.stride(0) if aux is not None else 0
+    g.out = out.data_ptr()
+    g.ldo = out.stride(0) if (out.dim() >= 2 and epi != EPI_EXPSUM) else 0
+    g.out2 = _p(out2)
+    g.ldo2 = out2.stride(0) if out2 is not None else 0
+    g.scale, g.act, g.rs_bias_only = scale, act, int(rs_bias_only)
+    if epi in (EPI_BF16, EPI_ACT, EPI_DACT):
+        _chk(out, BF16, "out")
+    else:
+        _chk(out, F32, "out")
+    check(lib.aim_gemm_bf16(byref(g), epi, batch, _stream()), "aim_gemm_bf16")
+    return out
+
+
+def expsum_tiles(M: int, N: int) -> int:
+    return load_library().aim_gemm_expsum_tiles(M, N)
+
+
+def wgrad(g: torch.Tensor, a: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None):
+    """``dw[n,k] += sum_m g[m,n] a[m,k]``; ``db[n] += sum_m g[m,n]`` (fp32 accumulate in place)."""
+    _chk(g, BF16, "g"); _chk(a, BF16, "a"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
+    assert g.shape[0] == a.shape[0] and dw.shape == (g.shape[1], a.shape[1])
+    check(load_library().aim_wgrad_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(),
+                                        dw.stride(0), _p(db), g.shape[0], g.shape[1], a.shape[1], _stream()),
+          "aim_wgrad_bf16")
+
+
+def layernorm_fwd(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, ldy=None, mean=None, rstd=None,
+                  eps: float = 1e-5):
+    _chk(x, F32, "x"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta")
+    _chk(y_bf16, BF16, "y_bf16"); _chk(y_f32, F32, "y_f32"); _chk(mean, F32, "mean"); _chk(rstd, F32, "rstd")
+    check(load_library().aim_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _p(y_bf16),
+                                           _p(y_f32), D if ldy is None else ldy, _p(mean), _p(rstd), rows, D,
+                                           eps, _stream()), "aim_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=None, dx=None, dx_bf16=None,
+                  dgamma=None, dbeta=None):
+    for n_, t_ in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dres", dres),
+                   ("dx", dx), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _chk(t_, F32, n_)
+    _chk(dx_bf16, BF16, "dx_bf16")
+    check(load_library().aim_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), _p(dres), _p(dx), _p(dx_bf16), lddx,
+                                           _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
+
+
+def attn_fwd(qkv, out, lse, BT, N, H):
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(lse, F32, "lse")
+    check(load_library().aim_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BT, N, H, _stream()),
+          "aim_attn_fwd")
+
+
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, BT, N, H):
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(dout, BF16, "dout"); _chk(dqkv, BF16, "dqkv")
+    _chk(lse, F32, "lse"); _chk(delta, F32, "delta")
+    check(load_library().aim_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                      delta.data_ptr(), dqkv.data_ptr(), BT, N, H, _stream()), "aim_attn_bwd")
+
+
+def cls_attn_fwd(qkv, out_cls, probs, B, T, N, H):
+    _chk(qkv, BF16, "qkv"); _chk(out_cls, BF16, "out_cls"); _chk(probs, F32, "probs")
+    check(load_library().aim_cls_attn_fwd(qkv.data_ptr(), out_cls.data_ptr(), probs.data_ptr(), B, T, N, H,
+                                          _stream()), "aim_cls_attn_fwd")
+
+
+def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H):
+    _chk(qkv, BF16, "qkv"); _chk(dout_cls, BF16, "dout_cls"); _chk(dqkv, BF16, "dqkv"); _chk(probs, F32, "probs")
+    check(load_library().aim_cls_attn_bwd(qkv.data_ptr(), probs.data_ptr(), dout_cls.data_ptr(), dqkv.data_ptr(),
+                                          B, T, N, H, _stream()), "aim_cls_attn_bwd")
+
+
+def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale):
+    _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(partials, F32, "partials"); _chk(lam, F32, "lam")
+    _chk(one_minus, F32, "one_minus")
+    check(load_library().aim_lambda(qkv.data_ptr(), kx.data_ptr(), partials.data_ptr(), ntiles, lam.data_ptr(),
+                                    _p(one_minus), BT, N, D, scale, _stream()), "aim_lambda")
+
+
+_IN_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.bfloat16: 2}
+
+
+def patchify(imgs, A, B, T, H, W, p, Kp, mean3=None, std3=None):
+    if imgs.dtype not in _IN_DTYPES:
+        raise TypeError(f"patchify: unsupported input dtype {imgs.dtype} (float32, uint8, bfloat16)")
+    if not imgs.is_cuda or not imgs.is_contiguous():
+        raise ValueError("patchify: imgs must be a contiguous GPU tensor")
+    _chk(A, BF16, "A"); _chk(mean3, F32, "mean3"); _chk(std3, F32, "std3")
+    check(load_library().aim_patchify(imgs.data_ptr(), _IN_DTYPES[imgs.dtype], _p(mean3), _p(std3), A.data_ptr(),
+                                      B, T, H, W, p, Kp, _stream()), "aim_patchify")
+
+
+def embed_ln(tok, cls, pos, temporal, gamma, beta, x, mean, rstd, B, T, N, D, eps=1e-5):
+    _chk(tok, BF16, "tok")
+    for n_, t_ in (("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("beta", beta), ("x", x),
+                   ("mean", mean), ("rstd", rstd)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_embed_ln(tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), temporal.data_ptr(),
+                                      gamma.data_ptr(), beta.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), B, T, N, D, eps, _stream()), "aim_embed_ln")
+
+
+def embed_bwd(dx, tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D):
+    _chk(tok, BF16, "tok")
+    for n_, t_ in (("dx", dx), ("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("mean", mean),
+                   ("rstd", rstd), ("dtemporal", dtemporal)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_embed_bwd(dx.data_ptr(), tok.data_ptr(), cls.data_ptr(), pos.data_ptr(),
+                                       temporal.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       dtemporal.data_ptr(), B, T, N, D, _stream()), "aim_embed_bwd")
+
+
+def frame_sum(x, w, out, frames, ntok, D):
+    _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(out, F32, "out")
+    check(load_library().aim_frame_sum(x.data_ptr(), _p(w), out.data_ptr(), frames, ntok, D, _stream()),
+          "aim_frame_sum")
+
+
+def colsum(X, out, *, af=None, at=None, ntok=0):
+    _chk(X, BF16, "X"); _chk(out, F32, "out"); _chk(af, F32, "af"); _chk(at, F32, "at")
+    check(load_library().aim_colsum_bf16(X.data_ptr(), X.stride(0), _p(af), _p(at), ntok, out.data_ptr(),
+                                         X.shape[0], X.shape[1], _stream()), "aim_colsum_bf16")
+
+
+def cast_bf16(src, dst, transpose=False):
+    _chk(src, F32, "src"); _chk(dst, BF16, "dst")
+    R, C = src.shape
+    check(load_library().aim_cast_bf16(src.data_ptr(), dst.data_ptr(), R, C, int(transpose), _stream()),
+          "aim_cast_bf16")
+
+
+def scale_rows(x, s, y=None, y_f32=None):
+    _chk(x, F32, "x"); _chk(s, F32, "s"); _chk(y, BF16, "y"); _chk(y_f32, F32, "y_f32")
+    R, C = x.shape
+    check(load_library().aim_scale_rows(x.data_ptr(), s.data_ptr(), _p(y), _p(y_f32), R, C, _stream()),
+          "aim_scale_rows")

@@ -1,0 +1,172 @@
+/*
+ * aim_kernels.h -- C ABI of libaim_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * AIM ViT-CLIP + Adapter forward/backward hot path.
+ *
+ * The reference (bobochow/adapt-image-models) is 100 % Python over PyTorch eager ops and has no
+ * FFI of its own; each entry point below replaces the eager-op sequence at the cited lines of
+ * mmaction/models/backbones/vit_clip.py.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success; non-zero -> aim_last_error() (thread-local text);
+ *   - all pointers are DEVICE pointers unless said otherwise; the caller owns all memory
+ *     (no allocation, no global state, no implicit synchronisation inside the library);
+ *   - `stream` is a hipStream_t passed as void*; launches are stream-ordered;
+ *   - matrices are row-major; "bf16" is IEEE bfloat16 stored as uint16_t; "ld*" are row strides
+ *     in ELEMENTS;
+ *   - token rows are frame-major: row = (b*T + t)*N + n for clip b, frame t, token n
+ *     (the reference's [N, BT, D] tensor transposed; N = (res/patch)^2 + 1, D = width);
+ *   - head_dim is 64 for every supported model (ViT-B/16: 12x64, ViT-L/14: 16x64).
+ */
+#ifndef AIM_KERNELS_H
+#define AIM_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t aim_bf16;
+
+#define AIM_ABI_VERSION 1
+
+int aim_version(void);                /* == AIM_ABI_VERSION */
+const char* aim_last_error(void);     /* message of the last failing call on this thread */
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[m][n] = sum_k A[m][k] * W[n][k]  (bf16 operands, fp32 accumulate, MFMA 16x16x32)
+ * replaces: q/k/v projections vit_clip.py:132-138,168-173; attn.out_proj :157,192;
+ *           mlp.c_fc/QuickGELU/c_proj :93-97,286; Adapter.D_fc1/GELU/D_fc2 :62-64;
+ *           residual combines :275,286; and (autograd) the dgrad of every frozen Linear
+ *           (pass the transposed weight).
+ * Requirements: K, lda, ldw multiples of 8; N, ldo (and ldo2/ldr/ldv/ldaux when used) multiples
+ * of 4; pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    AIM_EPI_BF16 = 0,  /* out(bf16) = rs * (acc + bias)                                         */
+    AIM_EPI_ACT = 1,   /* out2(bf16) = pre = acc + bias ; out(bf16) = rs * act(pre)             */
+    AIM_EPI_DACT = 2,  /* out(bf16) = rs * (acc + bias) * act'(aux)        (aux = saved pre)    */
+    AIM_EPI_F32 = 3,   /* out(f32) = resid + rs*(acc + bias) + bt[tok]*vec[frame][n]
+                          (rs_bias_only != 0: out = resid + acc + rs*bias + ...)               */
+    AIM_EPI_EXPSUM = 4 /* out(f32)[batch][tile][2] = (max, sum exp(scale*acc - max)) over the
+                          valid part of each 128x128 tile (lambda statistics, :149-151)         */
+};
+enum { AIM_ACT_QGELU = 0, AIM_ACT_GELU = 1 };
+
+typedef struct aim_gemm_args {
+    const aim_bf16* A;      /* [batch][M, lda]                                                  */
+    const aim_bf16* W;      /* [batch][N, ldw]                                                  */
+    int32_t lda, ldw;
+    int64_t strideA, strideW; /* batch strides in elements (0 for batch == 1)                   */
+    int32_t M, N, K;
+    const float* bias;      /* [N] or NULL                                                      */
+    const float* resid;     /* [M, ldr] f32 or NULL (AIM_EPI_F32)                               */
+    int32_t ldr;
+    /* row factor rs = af[row / ntok] * at[row % ntok]  (either may be NULL -> 1)               */
+    const float* af;        /* [M / ntok] per-frame factor, e.g. 1 - lamda                      */
+    const float* at;        /* [ntok]     per-token factor, e.g. DropPath mask * adapter scale  */
+    const float* vec;       /* [M / ntok, ldv] per-frame row vector added to every token        */
+    const float* bt;        /* [ntok] factor on vec (NULL -> 1)                                 */
+    int32_t ldv, ntok;
+    const aim_bf16* aux;    /* [M, ldaux] saved pre-activation (AIM_EPI_DACT)                   */
+    int32_t ldaux;
+    void* out;  int32_t ldo;
+    void* out2; int32_t ldo2;
+    float scale;            /* logit scale (AIM_EPI_EXPSUM)                                     */
+    int32_t act;            /* AIM_ACT_*                                                        */
+    int32_t rs_bias_only;   /* AIM_EPI_F32: apply rs to the bias term only                      */
+} aim_gemm_args;
+
+int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
+/* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
+int aim_gemm_expsum_tiles(int M, int N);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight-gradient GEMM for the (trainable) adapters:
+ *   dW[n][k] += sum_m G[m][n] * A[m][k]      db[n] += sum_m G[m][n]        (fp32 atomics)
+ * autograd counterpart of Adapter.D_fc1 / D_fc2 (vit_clip.py:57-58).  Nw, Kw multiples of 8.
+ * ------------------------------------------------------------------------------------------ */
+int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw,
+                   float* db, int M, int Nw, int Kw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 statistics, eps inside rsqrt) -- vit_clip.py:71-77 (ln_1, ln_2, ln_pre, ln_post)
+ *   fwd: y = (x - mean) * rstd * gamma + beta ; x fp32 rows with stride ldx; y as bf16 and/or f32
+ *   bwd: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma   (frozen gamma)
+ *        optional: dgamma/dbeta accumulation (fp32 atomics) for the trainable ln_post.
+ * ------------------------------------------------------------------------------------------ */
+int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      aim_bf16* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
+                      int rows, int D, float eps, void* stream);
+int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, const float* dres, float* dx,
+                      aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta,
+                      int rows, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spatial multi-head self-attention over the N tokens of each frame (flash-style, scores never
+ * leave the CU) -- vit_clip.py:139-156 (reshape, q k^T / sqrt(dh), softmax, @ v, merge heads).
+ *   qkv [BT*N, 3*D] bf16 (q | k | v, D = H*64) ; out [BT*N, D] bf16 ; lse [BT, H, N] f32
+ *   bwd: dqkv [BT*N, 3*D] bf16 from dout [BT*N, D] bf16 (recomputes the probabilities from lse).
+ * ------------------------------------------------------------------------------------------ */
+int aim_attn_fwd(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, void* stream);
+int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_bf16* dout, const float* lse,
+                 float* delta /* scratch [BT, H, N] f32 */, aim_bf16* dqkv, int BT, int N, int H,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Temporal attention over the T class tokens of each clip -- vit_clip.py:220-224 with
+ * attention() :139-156 at seq = T, batch = B.  Reads the class rows (token 0) of qkv.
+ *   out_cls [B*T, D] bf16 ; probs [B, H, T, T] f32 (saved for backward)
+ *   bwd: ADDS dq/dk/dv of the class rows into dqkv [BT*N, 3*D] (bf16, rows n == 0).
+ * ------------------------------------------------------------------------------------------ */
+int aim_cls_attn_fwd(const aim_bf16* qkv, aim_bf16* out_cls, float* probs, int B, int T, int N, int H,
+                     void* stream);
+int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout_cls, aim_bf16* dqkv,
+                     int B, int T, int N, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * lamda = cw / (cw + ow) per frame -- vit_clip.py:149-151, 184-186, 272.
+ *   ow[bt] = sum_{i,j} exp(q_i . k_j / 8)  arrives as AIM_EPI_EXPSUM partial pairs
+ *            partials [BT, ntiles, 2];  cw[bt] = sum_i exp(q_i . kx[bt] / 8) is computed here.
+ *   Both sums share one max shift (identical ratio, no overflow).  lam [BT] f32; one_minus [BT].
+ * ------------------------------------------------------------------------------------------ */
+int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, const float* partials, int ntiles,
+               float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch embedding glue -- vit_clip.py:434-447.
+ *   patchify: imgs [B,3,T,H,W] (f32, or uint8 with GPUNormalize mean/std fused:
+ *             mmaction/utils/module_hooks.py:73-85) -> A [B*T*G*G, Kp] bf16, Kp = 3*p*p padded
+ *             to a multiple of 64 with zeros (conv1 as a GEMM against conv1.weight.view(D,-1)).
+ *   embed_ln: tok [B*T*G*G, D] bf16 + class/positional/temporal embeddings -> ln_pre ->
+ *             x [B*T, N, D] f32 ; saves mean/rstd [B*T*N].
+ *   embed_bwd: d(temporal_embedding)[T, D] += sum_{b,n} ln_pre_bwd(dx)  (fp32 atomics).
+ * ------------------------------------------------------------------------------------------ */
+int aim_patchify(const void* imgs, int in_dtype /* 0 f32, 1 uint8, 2 bf16 */, const float* mean3, const float* std3, aim_bf16* A,
+                 int B, int T, int H, int W, int p, int Kp, void* stream);
+int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* pos, const float* temporal,
+                 const float* gamma, const float* beta, float* x, float* mean, float* rstd,
+                 int B, int T, int N, int D, float eps, void* stream);
+int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const float* pos,
+                  const float* temporal, const float* gamma, const float* mean, const float* rstd,
+                  float* dtemporal, int B, int T, int N, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small reductions / casts used by the block's backward and the optimizer boundary.
+ *   frame_sum : out[frame][d] = sum_tok w[tok] * x[frame*ntok + tok][d]   (x f32, w may be NULL)
+ *   colsum    : out[c] += sum_m rs(m) * X[m][c]   (X bf16; rs as in the GEMM; fp32 atomics)
+ *   cast      : f32 -> bf16 (optionally transposed [R,C] -> [C,R]) for weight staging
+ *   scale_rows: y[r][c] = s[r] * x[r][c]  (f32 x -> bf16 y), used for lamda * crs_attn
+ * ------------------------------------------------------------------------------------------ */
+int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream);
+int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok,
+                    float* out, int M, int C, void* stream);
+int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, void* stream);
+int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIM_KERNELS_H */

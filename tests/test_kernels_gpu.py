@@ -1,0 +1,342 @@
+"""Kernel-level numerics on a real MI355X: each HIP kernel (called through the C ABI) against a plain
+PyTorch fp32 restatement of the same op on the same bf16-rounded inputs.  Tolerances are written
+next to each check: bf16 outputs are allowed one bf16 ulp (2^-8 relative) plus accumulation noise."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from aim_amd import ops
+    return ops
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, ref, atol, rtol, what=""):
+    got, ref = got.float(), ref.float()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max err {err.max().item():.4e} "
+                           f"(ref max {ref.abs().max().item():.3e}) at {torch.nonzero(bad)[0].tolist()}")
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+# ------------------------------------------------------------------ GEMM -----------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (20, 32, 128), (100, 192, 136),
+                                   (394, 2304, 768), (130, 132, 72), (1, 4, 8)])
+def test_gemm_bf16_plain(M, N, K):
+    ops = _ops()
+    a, w = rnd((M, K), 1, dtype=torch.bfloat16), rnd((N, K), 2, K ** -0.5, torch.bfloat16)
+    bias = rnd((N,), 3)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, w, ops.EPI_BF16, out, bias=bias)
+    ref = a.float() @ w.float().T + bias
+    close(out, ref, 2e-3, 1e-2, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_strided_and_rowscale():
+    ops = _ops()
+    ntok, frames, N, K = 5, 6, 64, 128
+    M = ntok * frames
+    big = rnd((M, 3 * K), 4, dtype=torch.bfloat16)
+    a = big[:, K:2 * K]                      # row stride 3K, column offset K
+    w = rnd((N, K), 5, K ** -0.5, torch.bfloat16)
+    af, at = rnd((frames,), 6), rnd((ntok,), 7)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, w, ops.EPI_BF16, out, af=af, at=at, ntok=ntok)
+    rs = (af[:, None] * at[None, :]).reshape(M, 1)
+    close(out, rs * (a.float() @ w.float().T), 2e-3, 1e-2, "gemm strided+rowscale")
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_act_and_dact(act):
+    ops = _ops()
+    M, N, K = 200, 192, 128
+    a, w = rnd((M, K), 8, dtype=torch.bfloat16), rnd((N, K), 9, K ** -0.5, torch.bfloat16)
+    bias = rnd((N,), 10, 0.1)
+    post = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    pre = torch.zeros_like(post)
+    ops.gemm(a, w, ops.EPI_ACT, post, bias=bias, out2=pre, act=act)
+    pre_ref = a.float() @ w.float().T + bias
+    close(pre, pre_ref, 2e-3, 1e-2, "act pre")
+    f = quick_gelu if act == 0 else torch.nn.functional.gelu
+    close(post, f(pre.float()), 2e-3, 1e-2, "act post")       # applied to the bf16-rounded pre
+    # DACT: out = (g @ w2.T) * act'(pre)
+    g, w2 = rnd((M, K), 11, dtype=torch.bfloat16), rnd((N, K), 12, K ** -0.5, torch.bfloat16)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(g, w2, ops.EPI_DACT, out, aux=pre, act=act)
+    x = pre.float().requires_grad_(True)
+    f(x).sum().backward()
+    close(out, (g.float() @ w2.float().T) * x.grad, 3e-3, 1.5e-2, "dact")
+
+
+def test_gemm_f32_residual_forms():
+    ops = _ops()
+    ntok, frames, N, K = 7, 4, 128, 192
+    M = ntok * frames
+    a, w = rnd((M, K), 13, dtype=torch.bfloat16), rnd((N, K), 14, K ** -0.5, torch.bfloat16)
+    bias, resid = rnd((N,), 15), rnd((M, N), 16)
+    af, at, bt_, vec = rnd((frames,), 17), rnd((ntok,), 18), rnd((ntok,), 19), rnd((frames, N), 20)
+    acc = a.float() @ w.float().T
+    rs = (af[:, None] * at[None, :]).reshape(M, 1)
+    vterm = (bt_[None, :, None] * vec[:, None, :]).reshape(M, N)
+    out = torch.zeros((M, N), device=DEV)
+    ops.gemm(a, w, ops.EPI_F32, out, bias=bias, resid=resid, af=af, at=at, vec=vec, bt=bt_, ntok=ntok)
+    close(out, resid + rs * (acc + bias) + vterm, 1e-4, 1e-4, "f32 full")
+    ops.gemm(a, w, ops.EPI_F32, out, bias=bias, resid=resid, at=at, ntok=ntok, rs_bias_only=True)
+    close(out, resid + acc + at.repeat(frames)[:, None] * bias, 1e-4, 1e-4, "f32 rs_bias_only")
+    ops.gemm(a, w, ops.EPI_F32, out)
+    close(out, acc, 1e-4, 1e-4, "f32 plain")
+    # in-place accumulate (resid is out)
+    ref2 = out.clone() + acc
+    ops.gemm(a, w, ops.EPI_F32, out, resid=out)
+    close(out, ref2, 1e-4, 1e-4, "f32 accumulate in place")
+
+
+def test_gemm_expsum_batched():
+    ops = _ops()
+    BT, N, D = 3, 197, 256
+    qkv = rnd((BT * N, 3 * D), 21, 0.5, torch.bfloat16)
+    nt = ops.expsum_tiles(N, N)
+    part = torch.zeros((BT, nt, 2), device=DEV)
+    q, k = qkv[:, :D], qkv[:, D:2 * D]
+    ops.gemm(q, k, ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D, stride_w=N * 3 * D,
+             scale=0.125)
+    s = torch.einsum("bik,bjk->bij", q.float().reshape(BT, N, D), k.float().reshape(BT, N, D)) * 0.125
+    ref = torch.logsumexp(s.reshape(BT, -1), dim=1)
+    got = torch.logsumexp(part[..., 0] + torch.log(part[..., 1]), dim=1)
+    close(got, ref, 1e-4, 1e-5, "expsum logsumexp")
+
+
+# ------------------------------------------------------------------ LayerNorm ------------------
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 768), (33, 1024)])
+def test_layernorm_fwd_bwd(rows, D):
+    ops = _ops()
+    x = rnd((rows, D), 30, 2.0) + 0.5
+    gamma, beta = rnd((D,), 31) * 0.1 + 1, rnd((D,), 32, 0.1)
+    yb = torch.zeros((rows, D), dtype=torch.bfloat16, device=DEV)
+    yf = torch.zeros((rows, D), device=DEV)
+    mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, rows, D, D, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    close(yf, ref, 2e-6, 2e-6, "ln fwd f32")
+    close(yb, ref, 1e-6, 2 ** -8, "ln fwd bf16")
+    dy, dres = rnd((rows, D), 33), rnd((rows, D), 34)
+    ref.backward(dy)
+    dx = torch.zeros((rows, D), device=DEV)
+    dxb = torch.zeros((rows, D), dtype=torch.bfloat16, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, lddy=D, ldx=D, lddx=D, dres=dres, dx=dx, dx_bf16=dxb,
+                      dgamma=dg, dbeta=db)
+    close(dx, xr.grad + dres, 2e-5, 1e-5, "ln bwd dx")
+    close(dxb, xr.grad + dres, 1e-5, 2 ** -8, "ln bwd dx bf16")
+    close(dg, gr.grad, 1e-3, 1e-4, "ln dgamma")
+    close(db, br.grad, 1e-3, 1e-4, "ln dbeta")
+
+
+def test_layernorm_strided_rows():
+    """ln_post reads only the class rows: row stride N*D."""
+    ops = _ops()
+    BT, N, D = 6, 5, 128
+    x = rnd((BT, N, D), 35)
+    gamma, beta = rnd((D,), 36) + 1, rnd((D,), 37)
+    y = torch.zeros((BT, D), device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, BT, D, N * D, y_f32=y)
+    close(y, torch.nn.functional.layer_norm(x[:, 0], (D,), gamma, beta, 1e-5), 2e-6, 2e-6, "ln strided")
+
+
+# ------------------------------------------------------------------ attention ------------------
+def _attn_ref(qkv, BT, N, H):
+    D = H * 64
+    q, k, v = [t.reshape(BT, N, H, 64).permute(0, 2, 1, 3) for t in qkv.float().split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) / 8.0
+    p = s.softmax(-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(BT * N, D)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("BT,N,H", [(2, 5, 2), (3, 50, 1), (4, 197, 12), (2, 257, 4), (1, 16, 1)])
+def test_attn_fwd_bwd(BT, N, H):
+    ops = _ops()
+    D = H * 64
+    qkv = rnd((BT * N, 3 * D), 40, 1.0, torch.bfloat16)
+    out = torch.full((BT * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((BT, H, N), device=DEV)
+    ops.attn_fwd(qkv, out, lse, BT, N, H)
+    x = qkv.float().requires_grad_(True)
+    ref, lse_ref = _attn_ref(x, BT, N, H)
+    close(lse, lse_ref, 2e-3, 1e-4, "attn lse")
+    close(out, ref, 6e-3, 1.5e-2, "attn out")     # P is rounded to bf16 before P@V
+    do = rnd((BT * N, D), 41, 1.0, torch.bfloat16)
+    ref.backward(do.float())
+    dqkv = torch.full((BT * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros((BT, H, N), device=DEV)
+    ops.attn_bwd(qkv, out, do, lse, delta, dqkv, BT, N, H)
+    g = x.grad
+    scale = g.abs().max().item()
+    close(dqkv, g, 2e-2 * scale, 3e-2, "attn dqkv")
+
+
+def test_attn_large_logits():
+    """max-subtraction: logits of magnitude ~60 must not overflow."""
+    ops = _ops()
+    BT, N, H = 1, 40, 1
+    qkv = rnd((BT * N, 192), 42, 3.0, torch.bfloat16)
+    out = torch.zeros((BT * N, 64), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((BT, H, N), device=DEV)
+    ops.attn_fwd(qkv, out, lse, BT, N, H)
+    ref, lse_ref = _attn_ref(qkv, BT, N, H)
+    close(lse, lse_ref, 5e-3, 1e-4, "attn lse large")
+    close(out, ref, 3e-2, 3e-2, "attn out large")
+
+
+@pytest.mark.parametrize("B,T,N,H", [(2, 2, 5, 2), (3, 8, 7, 12), (1, 32, 3, 1)])
+def test_cls_attn(B, T, N, H):
+    ops = _ops()
+    D = H * 64
+    BT = B * T
+    qkv = rnd((BT * N, 3 * D), 43, 1.0, torch.bfloat16)
+    out = torch.zeros((BT, D), dtype=torch.bfloat16, device=DEV)
+    probs = torch.zeros((B, H, T, T), device=DEV)
+    ops.cls_attn_fwd(qkv, out, probs, B, T, N, H)
+    x = qkv.float().requires_grad_(True)
+    c = x.reshape(BT, N, 3 * D)[:, 0]                                  # class rows
+    q, k, v = [t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in c.split(D, dim=1)]
+    p = (q @ k.transpose(-1, -2) / 8.0).softmax(-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(BT, D)
+    close(probs, p, 1e-5, 1e-4, "cls probs")
+    close(out, ref, 2e-3, 2 ** -7, "cls out")
+    do = rnd((BT, D), 44, 1.0, torch.bfloat16)
+    ref.backward(do.float())
+    base = rnd((BT * N, 3 * D), 45, 1.0, torch.bfloat16)
+    dqkv = base.clone()
+    ops.cls_attn_bwd(qkv, probs, do, dqkv, B, T, N, H)
+    close(dqkv, base.float() + x.grad, 2e-2, 2e-2, "cls dqkv (accumulated into class rows)")
+
+
+def test_lambda():
+    ops = _ops()
+    BT, N, D = 4, 197, 768
+    qkv = rnd((BT * N, 3 * D), 46, 0.35, torch.bfloat16)
+    kx = rnd((BT, D), 47, 0.5, torch.bfloat16)
+    nt = ops.expsum_tiles(N, N)
+    part = torch.zeros((BT, nt, 2), device=DEV)
+    q, k = qkv[:, :D], qkv[:, D:2 * D]
+    ops.gemm(q, k, ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D, stride_w=N * 3 * D,
+             scale=0.125)
+    lam, oml = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
+    ops.lambda_(qkv, kx, part, nt, lam, oml, BT, N, D, 0.125)
+    qf, kf = q.float().reshape(BT, N, D).double(), k.float().reshape(BT, N, D).double()
+    ow = torch.exp(qf @ kf.transpose(1, 2) * 0.125).sum((1, 2))
+    cw = torch.exp((qf @ kx.double().unsqueeze(-1)).squeeze(-1) * 0.125).sum(1)
+    ref = (cw / (cw + ow)).float()
+    close(lam, ref, 1e-7, 2e-4, "lambda")
+    close(oml, 1 - ref, 1e-6, 1e-5, "1-lambda")
+
+
+# ------------------------------------------------------------------ wgrad ----------------------
+@pytest.mark.parametrize("M,Nw,Kw", [(64, 128, 128), (1000, 192, 768), (20, 32, 128), (4100, 768, 192), (512, 8, 16)])
+def test_wgrad(M, Nw, Kw):
+    ops = _ops()
+    g, a = rnd((M, Nw), 50, 1.0, torch.bfloat16), rnd((M, Kw), 51, 1.0, torch.bfloat16)
+    dw0, db0 = rnd((Nw, Kw), 52), rnd((Nw,), 53)
+    dw, db = dw0.clone(), db0.clone()
+    ops.wgrad(g, a, dw, db)
+    ref = dw0 + g.float().T @ a.float()
+    tol = 2e-5 * math.sqrt(M) * 4
+    close(dw, ref, tol + 1e-4, 1e-4, "wgrad dW")
+    close(db, db0 + g.float().sum(0), tol + 1e-4, 1e-4, "wgrad db")
+
+
+# ------------------------------------------------------------------ embed / misc ---------------
+@pytest.mark.parametrize("p,res", [(16, 32), (14, 28)])
+def test_patchify_and_embed(p, res):
+    ops = _ops()
+    B, T, D = 2, 3, 128
+    G = res // p
+    N = G * G + 1
+    K = 3 * p * p
+    Kp = (K + 63) // 64 * 64
+    imgs = rnd((B, 3, T, res, res), 60)
+    A = torch.full((B * T * G * G, Kp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.patchify(imgs, A, B, T, res, res, p, Kp)
+    ref = imgs.permute(0, 2, 1, 3, 4).reshape(B * T, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T * G * G, K)
+    close(A[:, :K], ref, 1e-6, 2 ** -8, "patchify")
+    assert (A[:, K:] == 0).all()
+    # uint8 + GPUNormalize fused
+    u8 = (torch.rand((B, 3, T, res, res), generator=torch.Generator().manual_seed(61)) * 255).to(torch.uint8).to(DEV)
+    mean3 = torch.tensor([122.769, 116.74, 104.04], device=DEV)
+    std3 = torch.tensor([68.493, 66.63, 70.321], device=DEV)
+    ops.patchify(u8, A, B, T, res, res, p, Kp, mean3, std3)
+    nrm = (u8.float() - mean3.view(1, 3, 1, 1, 1)) / std3.view(1, 3, 1, 1, 1)
+    ref = nrm.permute(0, 2, 1, 3, 4).reshape(B * T, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T * G * G, K)
+    close(A[:, :K], ref, 1e-6, 2 ** -8, "patchify uint8+normalize")
+    # embed + ln_pre, and its backward into temporal_embedding
+    tok = rnd((B * T * G * G, D), 62, 1.0, torch.bfloat16)
+    cls, pos = rnd((D,), 63), rnd((N, D), 64)
+    tmp = rnd((T, D), 65).requires_grad_(True)
+    gamma, beta = rnd((D,), 66) + 1, rnd((D,), 67)
+    x = torch.zeros((B * T, N, D), device=DEV)
+    mean, rstd = torch.zeros(B * T * N, device=DEV), torch.zeros(B * T * N, device=DEV)
+    ops.embed_ln(tok, cls, pos, tmp.detach(), gamma, beta, x, mean, rstd, B, T, N, D)
+    pre = torch.cat([cls.expand(B * T, 1, D), tok.float().reshape(B * T, G * G, D)], 1) + pos
+    pre = (pre.reshape(B, T, N, D) + tmp.reshape(1, T, 1, D)).reshape(B * T, N, D)
+    ref = torch.nn.functional.layer_norm(pre, (D,), gamma, beta, 1e-5)
+    close(x, ref, 5e-6, 5e-6, "embed_ln")
+    dx = rnd((B * T, N, D), 68)
+    ref.backward(dx)
+    dtmp = torch.zeros((T, D), device=DEV)
+    ops.embed_bwd(dx, tok, cls, pos, tmp.detach(), gamma, mean, rstd, dtmp, B, T, N, D)
+    close(dtmp, tmp.grad, 2e-4, 1e-4, "embed_bwd dtemporal")
+
+
+def test_misc_reductions_and_casts():
+    ops = _ops()
+    frames, ntok, D = 5, 7, 192
+    x, w = rnd((frames * ntok, D), 70), rnd((ntok,), 71)
+    out = torch.zeros((frames, D), device=DEV)
+    ops.frame_sum(x, w, out, frames, ntok, D)
+    close(out, (x.reshape(frames, ntok, D) * w[None, :, None]).sum(1), 1e-5, 1e-5, "frame_sum")
+    X = rnd((frames * ntok, D), 72, 1.0, torch.bfloat16)
+    af, at = rnd((frames,), 73), rnd((ntok,), 74)
+    cs = torch.zeros(D, device=DEV)
+    ops.colsum(X, cs, af=af, at=at, ntok=ntok)
+    rs = (af[:, None] * at[None, :]).reshape(-1, 1)
+    close(cs, (rs * X.float()).sum(0), 1e-4, 1e-4, "colsum")
+    src = rnd((50, 72), 75)
+    d1 = torch.zeros((50, 72), dtype=torch.bfloat16, device=DEV)
+    d2 = torch.zeros((72, 50), dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(src, d1)
+    ops.cast_bf16(src, d2, transpose=True)
+    assert torch.equal(d1, src.to(torch.bfloat16)) and torch.equal(d2, src.T.contiguous().to(torch.bfloat16))
+    s = rnd((50,), 76)
+    y = torch.zeros((50, 72), dtype=torch.bfloat16, device=DEV)
+    ops.scale_rows(src, s, y=y)
+    close(y, src * s[:, None], 1e-6, 2 ** -8, "scale_rows")
+
+
+def test_errors_are_loud():
+    ops = _ops()
+    a = torch.zeros((8, 12), dtype=torch.bfloat16, device=DEV)   # K=12 not a multiple of 8
+    w = torch.zeros((8, 12), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.gemm(a, w, ops.EPI_BF16, torch.zeros((8, 8), dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.gemm(a.cpu(), w, ops.EPI_BF16, torch.zeros((8, 8), dtype=torch.bfloat16, device=DEV))
