@@ -11,3 +11,15 @@ GPU) constructing the compute path raises.
 from .lib import load_library, library_path, LibraryNotBuilt  # noqa: F401
 
 __all__ = ["load_library", "library_path", "LibraryNotBuilt"]
+
+from .registry import (BACKBONES, HEADS, LOSSES, MODELS, RECOGNIZERS, Config, Registry,  # noqa: E402,F401
+                       build_backbone, build_from_cfg, build_head, build_loss, build_model, build_recognizer,
+                       register_into_mmaction)
+from .backbone import ViT_CLIP  # noqa: E402,F401
+from .recognizer import (CrossEntropyLoss, GPUNormalize, I3DHead, Recognizer3D,  # noqa: E402,F401
+                         register_module_hooks, top_k_accuracy)
+
+__all__ += ["BACKBONES", "HEADS", "LOSSES", "MODELS", "RECOGNIZERS", "Config", "Registry", "build_backbone",
+            "build_from_cfg", "build_head", "build_loss", "build_model", "build_recognizer", "register_into_mmaction",
+            "ViT_CLIP", "Recognizer3D", "I3DHead", "CrossEntropyLoss", "GPUNormalize", "register_module_hooks",
+            "top_k_accuracy"]

@@ -1,0 +1,525 @@
+"""``ViT_CLIP`` backbone (AIM ViT-CLIP + Adapters) on the HIP kernels of libaim_hip.so.
+
+Drop-in for ``mmaction/models/backbones/vit_clip.py:327-458`` of the reference: same registry name,
+same constructor keywords, same ``init_weights`` policy, same parameter names/shapes (so CLIP visual
+state_dicts and reference checkpoints load with ``strict=True``) and the same
+``forward(x[B,3,T,H,W]) -> [B,width,T,1,1]`` contract.  The arithmetic is NOT a translation of the
+reference's eager ops: the block is re-derived for a frame-major ``[B*T, N, D]`` layout with
+one ``ln_1``, one fused QKV projection, a collapsed single-key cross-attention and hand-written
+forward AND backward (frozen GEMMs need dgrad only) -- see DESIGN.md.
+
+There is no eager/CPU fallback: ``forward`` raises unless the input is on a GPU and the HIP
+library is built.
+"""
+import logging
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .registry import BACKBONES
+
+BF16, F32 = torch.bfloat16, torch.float32
+_LOG = logging.getLogger("aim_amd")
+
+
+def get_root_logger():
+    return _LOG
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers (names follow the reference so state_dicts interchange)
+# ----------------------------------------------------------------------------------------------
+class Adapter(nn.Module):
+    """Bottleneck adapter parameters (reference ``Adapter``, vit_clip.py:51-69)."""
+
+    def __init__(self, D_features: int, mlp_ratio: float = 0.25, skip_connect: bool = True):
+        super().__init__()
+        self.skip_connect = skip_connect
+        hidden = int(D_features * mlp_ratio)
+        self.D_fc1 = nn.Linear(D_features, hidden)
+        self.D_fc2 = nn.Linear(hidden, D_features)
+
+
+class LayerNorm(nn.LayerNorm):
+    """Parameter container; the fp32 LayerNorm itself runs in ``aim_layernorm_fwd`` (vit_clip.py:71-77)."""
+
+
+class QuickGELU(nn.Module):
+    """Placeholder so ``mlp`` keeps the reference's three-entry Sequential (vit_clip.py:80-82,93-97)."""
+
+
+class ResidualAttentionBlock(nn.Module):
+    """Parameters of one block (reference vit_clip.py:85-118); compute lives in ``_BackboneFn``."""
+
+    def __init__(self, d_model: int, n_head: int, scale: float = 1., num_frames: int = 8, drop_path: float = 0.):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)   # parameter container only, as in the reference
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([
+            ("c_fc", nn.Linear(d_model, d_model * 4)),
+            ("gelu", QuickGELU()),
+            ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = LayerNorm(d_model)
+        self.n_head = n_head
+        self.d_model = d_model
+        self.MLP_Adapter = Adapter(d_model, skip_connect=False)
+        self.S_Adapter = Adapter(d_model, skip_connect=False)
+        self.scale = scale
+        self.T_Adapter = Adapter(d_model, skip_connect=False)
+        self.num_frames = num_frames
+        self.drop_prob = float(drop_path)
+
+
+class Transformer(nn.Module):
+    def __init__(self, num_frames, width, layers, heads, scale=1., drop_path=0.1):
+        super().__init__()
+        self.width, self.layers = width, layers
+        dpr = [x.item() for x in torch.linspace(0, drop_path, layers)]   # vit_clip.py:297
+        self.resblocks = nn.Sequential(*[
+            ResidualAttentionBlock(width, heads, scale, num_frames, dpr[i]) for i in range(layers)])
+
+
+_ADAPTERS = ("MLP_Adapter", "S_Adapter", "T_Adapter")
+_ADAPTER_LEAVES = ("D_fc1.weight", "D_fc1.bias", "D_fc2.weight", "D_fc2.bias")
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 operand staging
+# ----------------------------------------------------------------------------------------------
+def _cast(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    w2 = w.detach().reshape(w.shape[0], -1).contiguous().float()
+    R, C = w2.shape
+    out = torch.empty((C, R) if transpose else (R, C), dtype=BF16, device=w.device)
+    ops.cast_bf16(w2, out, transpose)
+    return out
+
+
+class _Frozen:
+    """bf16 copies (and transposes, for dgrad) of one block's frozen weights; built once."""
+
+    def __init__(self, blk: ResidualAttentionBlock):
+        a = blk.attn
+        self.Wqkv, self.WqkvT = _cast(a.in_proj_weight), _cast(a.in_proj_weight, True)
+        self.Wo, self.WoT = _cast(a.out_proj.weight), _cast(a.out_proj.weight, True)
+        self.Wfc, self.WfcT = _cast(blk.mlp.c_fc.weight), _cast(blk.mlp.c_fc.weight, True)
+        self.Wpr, self.WprT = _cast(blk.mlp.c_proj.weight), _cast(blk.mlp.c_proj.weight, True)
+        f = lambda p: p.detach().float().contiguous()
+        self.bqkv, self.bo = f(a.in_proj_bias), f(a.out_proj.bias)
+        self.bfc, self.bpr = f(blk.mlp.c_fc.bias), f(blk.mlp.c_proj.bias)
+        self.g1, self.b1 = f(blk.ln_1.weight), f(blk.ln_1.bias)
+        self.g2, self.b2 = f(blk.ln_2.weight), f(blk.ln_2.bias)
+
+
+class _AdapterW:
+    """bf16 operands of one adapter for this step (weights are trainable: re-cast when they change)."""
+
+    def __init__(self, w1, b1, w2, b2):
+        self.W1, self.W1T = _cast(w1), _cast(w1, True)     # [r, D], [D, r]
+        self.W2, self.W2T = _cast(w2), _cast(w2, True)     # [D, r], [r, D]
+        self.b1, self.b2 = b1.detach().float().contiguous(), b2.detach().float().contiguous()
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+# ----------------------------------------------------------------------------------------------
+# one block: forward / backward on raw buffers
+# ----------------------------------------------------------------------------------------------
+def _adapter_fwd_small(x_bf, ad: _AdapterW, rows, r, D, dev, out_f32: bool):
+    """Adapter on a few rows (class-token / per-frame vectors): D_fc1 -> GELU(erf) -> D_fc2."""
+    pre, h = _empty((rows, r), BF16, dev), _empty((rows, r), BF16, dev)
+    ops.gemm(x_bf, ad.W1, ops.EPI_ACT, h, bias=ad.b1, out2=pre, act=ops.ACT_GELU)
+    out = _empty((rows, D), F32 if out_f32 else BF16, dev)
+    ops.gemm(h, ad.W2, ops.EPI_F32 if out_f32 else ops.EPI_BF16, out, bias=ad.b2)
+    return out, pre, h
+
+
+def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, dms2, save: bool):
+    """x: [B*T*N, D] f32 -> x2 (same shape).  Returns (x2, ctx) with ctx the tensors backward needs."""
+    dev = x.device
+    M, D = x.shape
+    BT = B * T
+    r = adp["MLP_Adapter"].W1.shape[0]
+    # ln_1 (once) + fused QKV projection
+    xl = _empty((M, D), BF16, dev)
+    mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
+    ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
+    qkv = _empty((M, 3 * D), BF16, dev)
+    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
+    del xl
+    # temporal attention over the class tokens + T_Adapter (vit_clip.py:220-229)
+    ot = _empty((BT, D), BF16, dev)
+    probs = _empty((B, H, T, T), F32, dev)
+    ops.cls_attn_fwd(qkv, ot, probs, B, T, N, H)
+    ta = _empty((BT, D), BF16, dev)
+    ops.gemm(ot, fz.Wo, ops.EPI_BF16, ta, bias=fz.bo)
+    xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, dev, out_f32=False)
+    # cross-attention to the single key/value xt[bt] (:265): softmax == 1, so crs = out_proj(W_v xt + b_v)
+    kv = _empty((BT, 2 * D), BF16, dev)
+    ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
+    crs = _empty((BT, D), F32, dev)
+    ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
+    # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
+    nt = ops.expsum_tiles(N, N)
+    part = _empty((BT, nt, 2), F32, dev)
+    ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
+             stride_w=N * 3 * D, scale=0.125)
+    lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
+    ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125)
+    # spatial attention (:264)
+    ao = _empty((M, D), BF16, dev)
+    lse = _empty((BT, H, N), F32, dev)
+    ops.attn_fwd(qkv, ao, lse, BT, N, H)
+    # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
+    sin = _empty((BT, D), BF16, dev)
+    ops.scale_rows(crs, lam, y=sin)
+    sv, s_pre, s_h = _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, dev, out_f32=True)
+    # x1 = x + (1 - lamda) * out_proj(ao) + drop_path(scale * s_vec)
+    x1 = _empty((M, D), F32, dev)
+    ops.gemm(ao, fz.Wo, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
+    # joint adaptation (:285-286)
+    xn = _empty((M, D), BF16, dev)
+    mean2, rstd2 = _empty((M,), F32, dev), _empty((M,), F32, dev)
+    ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
+    h_pre, h = _empty((M, 4 * D), BF16, dev), _empty((M, 4 * D), BF16, dev)
+    ops.gemm(xn, fz.Wfc, ops.EPI_ACT, h, bias=fz.bfc, out2=h_pre, act=ops.ACT_QGELU)
+    ma = adp["MLP_Adapter"]
+    a_pre, a_s = _empty((M, r), BF16, dev), _empty((M, r), BF16, dev)
+    ops.gemm(xn, ma.W1, ops.EPI_ACT, a_s, bias=ma.b1, out2=a_pre, act=ops.ACT_GELU, at=dms2, ntok=N)
+    x2 = _empty((M, D), F32, dev)
+    ops.gemm(h, fz.Wpr, ops.EPI_F32, x2, bias=fz.bpr, resid=x1)
+    del h
+    ops.gemm(a_s, ma.W2, ops.EPI_F32, x2, bias=ma.b2, resid=x2, at=dms2, ntok=N, rs_bias_only=True)
+    ctx = None
+    if save:
+        ctx = dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, probs=probs, ta=ta, t_pre=t_pre, t_h=t_h, lam=lam,
+                   oml=oml, ao=ao, lse=lse, sin=sin, s_pre=s_pre, s_h=s_h, x1=x1, mean2=mean2, rstd2=rstd2, xn=xn,
+                   h_pre=h_pre, a_pre=a_pre, a_s=a_s, dms1=dms1, dms2=dms2)
+    return x2, ctx
+
+
+def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, dev, need_dx_bf16: bool):
+    """Backward of an adapter on a few rows; accumulates its 4 parameter gradients, returns d(input)."""
+    ops.wgrad(dout_bf, h, grads["D_fc2.weight"], grads["D_fc2.bias"])
+    dpre = _empty((rows, r), BF16, dev)
+    ops.gemm(dout_bf, ad.W2T, ops.EPI_DACT, dpre, aux=pre, act=ops.ACT_GELU)
+    ops.wgrad(dpre, a_in, grads["D_fc1.weight"], grads["D_fc1.bias"])
+    din = _empty((rows, D), BF16 if need_dx_bf16 else F32, dev)
+    ops.gemm(dpre, ad.W1T, ops.EPI_BF16 if need_dx_bf16 else ops.EPI_F32, din)
+    return din
+
+
+def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T, N, H):
+    """dx2 [M, D] f32 and its bf16 copy dyb -> (dx, dx_bf16); adapter grads accumulated into ``grads``."""
+    dev = dx2.device
+    M, D = dx2.shape
+    BT = B * T
+    r = adp["MLP_Adapter"].W1.shape[0]
+    ma, gm = adp["MLP_Adapter"], grads["MLP_Adapter"]
+    # ---- MLP_Adapter: x2 += dms2[tok] * (gelu(xn W1^T + b1) W2^T + b2); a_s = dms2 * gelu(.)
+    ops.colsum(dyb, gm["D_fc2.bias"], at=c["dms2"], ntok=N)
+    ops.wgrad(dyb, c["a_s"], gm["D_fc2.weight"])
+    da_pre = _empty((M, r), BF16, dev)
+    ops.gemm(dyb, ma.W2T, ops.EPI_DACT, da_pre, aux=c["a_pre"], act=ops.ACT_GELU, at=c["dms2"], ntok=N)
+    ops.wgrad(da_pre, c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
+    # ---- frozen MLP (dgrad only)
+    dh_pre = _empty((M, 4 * D), BF16, dev)
+    ops.gemm(dyb, fz.WprT, ops.EPI_DACT, dh_pre, aux=c["h_pre"], act=ops.ACT_QGELU)
+    dxn = _empty((M, D), F32, dev)
+    ops.gemm(dh_pre, fz.WfcT, ops.EPI_F32, dxn)
+    del dh_pre
+    ops.gemm(da_pre, ma.W1T, ops.EPI_F32, dxn, resid=dxn)
+    del da_pre
+    # ---- ln_2
+    dx1, dx1b = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
+    ops.layernorm_bwd(dxn, c["x1"], fz.g2, c["mean2"], c["rstd2"], M, D, lddy=D, ldx=D, lddx=D, dres=dx2, dx=dx1,
+                      dx_bf16=dx1b)
+    del dxn
+    # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
+    dsv = _empty((BT, D), F32, dev)
+    ops.frame_sum(dx1, c["dms1"], dsv, BT, N, D)
+    dao = _empty((M, D), BF16, dev)
+    ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N)
+    del dx1b
+    dqkv = _empty((M, 3 * D), BF16, dev)
+    delta = _empty((BT, H, N), F32, dev)
+    ops.attn_bwd(c["qkv"], c["ao"], dao, c["lse"], delta, dqkv, BT, N, H)
+    del dao
+    # ---- S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
+    dsv_b = _empty((BT, D), BF16, dev)
+    ops.cast_bf16(dsv, dsv_b)
+    dsin = _adapter_bwd_small(dsv_b, adp["S_Adapter"], c["sin"], c["s_pre"], c["s_h"], grads["S_Adapter"], BT, r, D,
+                              dev, need_dx_bf16=False)
+    dcrs = _empty((BT, D), BF16, dev)
+    ops.scale_rows(dsin, c["lam"], y=dcrs)
+    dvx = _empty((BT, D), BF16, dev)
+    ops.gemm(dcrs, fz.WoT, ops.EPI_BF16, dvx)
+    dxt = _empty((BT, D), BF16, dev)
+    ops.gemm(dvx, fz.WqkvT[:, 2 * D:], ops.EPI_BF16, dxt)
+    # ---- T_Adapter and the temporal attention over class tokens
+    dta = _adapter_bwd_small(dxt, adp["T_Adapter"], c["ta"], c["t_pre"], c["t_h"], grads["T_Adapter"], BT, r, D, dev,
+                             need_dx_bf16=True)
+    dot = _empty((BT, D), BF16, dev)
+    ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
+    ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)
+    # ---- fused QKV projection (dgrad) and ln_1
+    dxl = _empty((M, D), F32, dev)
+    ops.gemm(dqkv, fz.WqkvT, ops.EPI_F32, dxl)
+    del dqkv
+    dx, dxb = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
+    ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1, dx=dx,
+                      dx_bf16=dxb)
+    return dx, dxb
+
+
+# ----------------------------------------------------------------------------------------------
+# whole backbone as one autograd node
+# ----------------------------------------------------------------------------------------------
+class _BackboneFn(torch.autograd.Function):
+    """imgs -> [B, D, T] features.  Differentiable inputs: temporal_embedding, ln_post.{weight,bias} and
+    the 12 adapter tensors of every layer (the reference's trainable set, vit_clip.py:413-415)."""
+
+    @staticmethod
+    def forward(ctx, model: "ViT_CLIP", imgs: torch.Tensor, *params: torch.Tensor):
+        L, H = model.layers, model.heads
+        B, C, T, Hh, Ww = imgs.shape
+        D, p = model.width, model.patch_size
+        G = Hh // p
+        N = G * G + 1
+        BT, M = B * T, B * T * N
+        dev = imgs.device
+        temporal, lnp_w, lnp_b = params[0], params[1], params[2]
+        need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in params)
+        frozen = model._frozen_operands()
+        adp = []
+        for i in range(L):
+            d = {}
+            for j, a in enumerate(_ADAPTERS):
+                k = 3 + (i * 3 + j) * 4
+                d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3])
+            adp.append(d)
+        # patch embedding as a GEMM (conv1: kernel = stride = patch, no bias; vit_clip.py:436)
+        Kp = frozen["conv"].shape[1]
+        A = _empty((BT * G * G, Kp), BF16, dev)
+        ops.patchify(imgs, A, B, T, Hh, Ww, p, Kp, model._norm_mean, model._norm_std)
+        tok = _empty((BT * G * G, D), BF16, dev)
+        ops.gemm(A, frozen["conv"], ops.EPI_BF16, tok)
+        del A
+        x = _empty((M, D), F32, dev)
+        mean0, rstd0 = _empty((M,), F32, dev), _empty((M,), F32, dev)
+        tmp = temporal.detach().reshape(T, D).float().contiguous()
+        ops.embed_ln(tok, frozen["cls"], frozen["pos"], tmp, frozen["gpre"], frozen["bpre"], x, mean0, rstd0, B, T, N, D)
+        # blocks
+        ctxs: List[Optional[dict]] = []
+        training = model.training
+        for i in range(L):
+            blk = model.transformer.resblocks[i]
+            dms1 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
+            dms2 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
+            x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad)
+            ctxs.append(c)
+        # ln_post on the class rows only (LayerNorm is per-row; vit_clip.py:452-453)
+        gw, gb = lnp_w.detach().float().contiguous(), lnp_b.detach().float().contiguous()
+        y = _empty((BT, D), F32, dev)
+        meanp, rstdp = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
+        ops.layernorm_fwd(x, gw, gb, BT, D, N * D, y_f32=y, mean=meanp, rstd=rstdp)
+        if need_grad:
+            ctx.model, ctx.dims = model, (B, T, N, H, D, L)
+            ctx.saved = dict(ctxs=ctxs, adp=adp, tok=tok, mean0=mean0, rstd0=rstd0, tmp=tmp, xL=x, gw=gw, meanp=meanp,
+                             rstdp=rstdp, params=params)
+        return y.reshape(B, T, D).permute(0, 2, 1)      # '(b t) d -> b d t'
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        B, T, N, H, D, L = ctx.dims
+        s = ctx.saved
+        BT, M = B * T, B * T * N
+        dev = dout.device
+        frozen = model._frozen_operands()
+        params = s["params"]
+        # gradient buffers (fp32, accumulated by atomics inside the kernels)
+        grads_out: List[Optional[torch.Tensor]] = [None] * len(params)
+        layer_grads = []
+        for i in range(L):
+            lg = {}
+            for j, a in enumerate(_ADAPTERS):
+                k = 3 + (i * 3 + j) * 4
+                lg[a] = {}
+                for e, leaf in enumerate(_ADAPTER_LEAVES):
+                    g = torch.zeros_like(params[k + e], dtype=F32)
+                    lg[a][leaf] = g
+                    grads_out[k + e] = g
+            layer_grads.append(lg)
+        dgw, dgb = torch.zeros(D, dtype=F32, device=dev), torch.zeros(D, dtype=F32, device=dev)
+        dy = dout.permute(0, 2, 1).reshape(BT, D).contiguous().float()
+        # ln_post backward touches the class rows only; every other row of the top gradient is zero
+        dx = torch.zeros((M, D), dtype=F32, device=dev)
+        dxb = torch.zeros((M, D), dtype=BF16, device=dev)
+        ops.layernorm_bwd(dy, s["xL"], s["gw"], s["meanp"], s["rstdp"], BT, D, lddy=D, ldx=N * D, lddx=N * D, dx=dx,
+                          dx_bf16=dxb, dgamma=dgw, dbeta=dgb)
+        for i in reversed(range(L)):
+            dx, dxb = _block_backward(dx, dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H)
+            s["ctxs"][i] = None
+        dtmp = torch.zeros((T, D), dtype=F32, device=dev)
+        ops.embed_bwd(dx, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"], dtmp,
+                      B, T, N, D)
+        grads_out[0] = dtmp.reshape(1, T, D)
+        grads_out[1], grads_out[2] = dgw, dgb
+        for k, p_ in enumerate(params):
+            if not p_.requires_grad:
+                grads_out[k] = None
+            elif grads_out[k] is not None and grads_out[k].dtype != p_.dtype:
+                grads_out[k] = grads_out[k].to(p_.dtype)
+        ctx.saved = None
+        return (None, None) + tuple(grads_out)
+
+
+@BACKBONES.register_module()
+class ViT_CLIP(nn.Module):
+    """ViT definition in CLIP image encoder + AIM adapters (reference vit_clip.py:327-458)."""
+
+    def __init__(self, input_resolution: int, num_frames: int, patch_size: int, width: int, layers: int, heads: int,
+                 drop_path_rate, adapter_scale=0.5, pretrained=None, shift=False, checkpoint=False):
+        super().__init__()
+        if shift:
+            # reference vit_clip.py:233-258: raises EinopsError at every supported resolution
+            raise NotImplementedError("ViT_CLIP(shift=True) is dead code in the reference and is not supported")
+        if width % heads != 0 or width // heads != 64:
+            raise ValueError("the HIP attention kernels are built for head_dim 64 (ViT-B/16, ViT-L/14)")
+        self.input_resolution = input_resolution
+        self.pretrained = pretrained
+        self.patch_size = patch_size
+        self.width, self.layers, self.heads = width, layers, heads
+        self.conv1 = nn.Conv2d(in_channels=3, out_channels=width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.num_frames = num_frames
+        self.temporal_embedding = nn.Parameter(torch.zeros(1, num_frames, width))
+        self.shift = shift
+        self.checkpoint = checkpoint   # accepted for config compatibility; activations fit in 288 GB HBM
+        self.transformer = Transformer(num_frames, width, layers, heads, scale=adapter_scale, drop_path=drop_path_rate)
+        self.ln_post = LayerNorm(width)
+        self._frozen_cache = None
+        self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
+
+    # ---- reference API ------------------------------------------------------------------------
+    def init_weights(self, pretrained=None):
+        """Reference ``init_weights`` (vit_clip.py:352-423): init, optional CLIP load, zero the adapters'
+        up-projections, freeze everything but temporal_embedding / ln_post / Adapters / cls_head."""
+        def _init_weights(m):
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+        if pretrained:
+            self.pretrained = pretrained
+        if isinstance(self.pretrained, str):
+            self.apply(_init_weights)
+            try:
+                import clip  # noqa: F401
+            except ImportError as e:
+                raise RuntimeError(
+                    "pretrained=%r needs the OpenAI `clip` package and its downloaded weights "
+                    "(reference vit_clip.py:369-372); load a CLIP visual state_dict with "
+                    "load_state_dict(strict=False) instead" % (self.pretrained,)) from e
+            name = "ViT-B/16" if self.layers == 12 else "ViT-L/14"
+            clip_model, _ = clip.load(name, device="cpu")
+            sd = clip_model.visual.state_dict()
+            del clip_model
+            del sd['proj']
+            msg = self.load_state_dict(sd, strict=False)
+            _LOG.info('Missing keys: %s', msg.missing_keys)
+            _LOG.info('Unexpected keys: %s', msg.unexpected_keys)
+        elif self.pretrained is None:
+            self.apply(_init_weights)
+        else:
+            raise TypeError('pretrained must be a str or None')
+        for n, m in self.transformer.named_modules():
+            if n.split(".")[-1] in _ADAPTERS:
+                nn.init.constant_(m.D_fc2.weight, 0)
+                nn.init.constant_(m.D_fc2.bias, 0)
+        for name, param in self.named_parameters():
+            if ('temporal_embedding' not in name and 'ln_post' not in name and 'Adapter' not in name
+                    and 'cls_head' not in name):
+                param.requires_grad = False
+        n_train = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        n_total = sum(p.numel() for p in self.parameters())
+        _LOG.info('Number of total parameters: %6.2f, tunable parameters: %6.2f', n_total / 1e6, n_train / 1e6)
+        self._frozen_cache = None
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed', 'temporal_embedding'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table', 'temporal_position_bias_table'}
+
+    # ---- operand staging ------------------------------------------------------------------------
+    def _frozen_params(self):
+        skip = set(id(p) for p in self._trainable_list())
+        return [p for p in self.parameters() if id(p) not in skip]
+
+    def _frozen_operands(self):
+        """bf16 copies of the frozen weights; rebuilt only when a frozen tensor changed or moved."""
+        key = tuple((p.data_ptr(), p._version) for p in self._frozen_params())
+        if self._frozen_cache is not None and self._frozen_cache[0] == key:
+            return self._frozen_cache[1]
+        D, p = self.width, self.patch_size
+        K = 3 * p * p
+        Kp = (K + 63) // 64 * 64
+        dev = self.conv1.weight.device
+        wc = torch.zeros((D, Kp), dtype=F32, device=dev)
+        wc[:, :K] = self.conv1.weight.detach().reshape(D, K).float()
+        conv = torch.empty((D, Kp), dtype=BF16, device=dev)
+        ops.cast_bf16(wc, conv)
+        f = lambda t: t.detach().float().contiguous()
+        out = dict(conv=conv, cls=f(self.class_embedding), pos=f(self.positional_embedding),
+                   gpre=f(self.ln_pre.weight), bpre=f(self.ln_pre.bias),
+                   blocks=[_Frozen(b) for b in self.transformer.resblocks])
+        self._frozen_cache = (key, out)
+        return out
+
+    def _trainable_list(self):
+        ps = [self.temporal_embedding, self.ln_post.weight, self.ln_post.bias]
+        for blk in self.transformer.resblocks:
+            for a in _ADAPTERS:
+                m = getattr(blk, a)
+                ps += [m.D_fc1.weight, m.D_fc1.bias, m.D_fc2.weight, m.D_fc2.bias]
+        return ps
+
+    @staticmethod
+    def _drop_mask(N, drop_prob, scale, training, dev):
+        """DropPath factor times adapter scale, per TOKEN index: timm's mask has shape (x.shape[0],1,1)
+        and the reference's x is [N, BT, D] (vit_clip.py:112,275,286)."""
+        if drop_prob > 0. and training:
+            keep = 1.0 - drop_prob
+            m = torch.empty(N, dtype=F32, device=dev).bernoulli_(keep)
+            return m.div_(keep).mul_(scale) if keep > 0 else m.mul_(0.)
+        return torch.full((N,), float(scale), dtype=F32, device=dev)
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("aim_amd.ViT_CLIP runs on MI355X only (HIP kernels); there is no CPU fallback")
+        B, C, T, H, W = x.shape
+        if T != self.num_frames:
+            raise ValueError(f"expected {self.num_frames} frames, got {T}")   # reference: einops error at :443
+        if C != 3 or H != self.input_resolution or W != self.input_resolution:
+            raise ValueError(f"expected input [B,3,{T},{self.input_resolution},{self.input_resolution}], got {tuple(x.shape)}")
+        if x.dtype == torch.float16:
+            x = x.float()
+        x = x.contiguous()
+        y = _BackboneFn.apply(self, x, *self._trainable_list())     # [B, D, T]
+        return y.unsqueeze(-1).unsqueeze(-1)                          # BDTHW for I3D head (:456)

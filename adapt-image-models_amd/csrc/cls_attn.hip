@@ -110,14 +110,14 @@ __global__ __launch_bounds__(64) void cls_attn_bwd_kernel(const bf16_t* __restri
 
 // one block (4 waves) per frame
 __global__ __launch_bounds__(256) void lambda_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx,
-                                                     const float* __restrict__ partials, int ntiles,
+                                                     int ldkx, const float* __restrict__ partials, int ntiles,
                                                      float* __restrict__ lam, float* __restrict__ oml, int N, int D,
                                                      float scale) {
     __shared__ float ss[320];
     __shared__ float red[8];
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = 3 * D;
-    const bf16_t* kr = kx + (long long)bt * D;
+    const bf16_t* kr = kx + (long long)bt * ldkx;
     for (int i = wave; i < N; i += 4) {
         const bf16_t* qr = qkv + ((long long)bt * N + i) * ld;
         float acc = 0.f;
@@ -181,12 +181,12 @@ extern "C" int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const a
     return 0;
 }
 
-extern "C" int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, const float* partials, int ntiles, float* lam,
+extern "C" int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* partials, int ntiles, float* lam,
                           float* one_minus_lam, int BT, int N, int D, float scale, void* stream) {
     AIM_CHECK_ARG(BT > 0 && N > 0 && N <= 320 && D > 0 && (D % 4) == 0, "lambda: unsupported shape BT=%d N=%d D=%d", BT, N, D);
-    AIM_CHECK_ARG(qkv && kx && partials && lam && ntiles > 0, "lambda: null pointer");
+    AIM_CHECK_ARG(qkv && kx && partials && lam && ntiles > 0 && ldkx >= D && (ldkx % 4) == 0, "lambda: bad arguments");
     hipLaunchKernelGGL(lambda_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (const bf16_t*)kx, partials, ntiles, lam, one_minus_lam, N, D, scale);
+                       (const bf16_t*)kx, ldkx, partials, ntiles, lam, one_minus_lam, N, D, scale);
     AIM_CHECK_LAUNCH("aim_lambda");
     return 0;
 }

@@ -136,7 +136,7 @@ def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H):
 def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale):
     _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(partials, F32, "partials"); _chk(lam, F32, "lam")
     _chk(one_minus, F32, "one_minus")
-    check(load_library().aim_lambda(qkv.data_ptr(), kx.data_ptr(), partials.data_ptr(), ntiles, lam.data_ptr(),
+    check(load_library().aim_lambda(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), partials.data_ptr(), ntiles, lam.data_ptr(),
                                     _p(one_minus), BT, N, D, scale, _stream()), "aim_lambda")
 
 

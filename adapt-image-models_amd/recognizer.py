@@ -1,0 +1,303 @@
+"""Callers either side of the backbone, mirroring the reference's interfaces for this path only:
+
+* ``Recognizer3D``  -- mmaction/models/recognizers/recognizer3d.py:8-118 + base.py:14-330
+* ``I3DHead``       -- mmaction/models/heads/i3d_head.py:9-73 + heads/base.py:27-108
+* ``CrossEntropyLoss`` -- mmaction/models/losses/cross_entropy_loss.py:9-80 (hard and soft labels)
+* ``top_k_accuracy``   -- mmaction/core/evaluation/accuracy.py:90-109
+* ``GPUNormalize`` / ``register_module_hooks`` -- mmaction/utils/module_hooks.py:8-87 (fused into the
+  patch-embedding kernel when the hooked module is this package's ``ViT_CLIP``).
+
+These are thin plain-PyTorch host modules (a few hundred kFLOP per step); the hot path is the
+backbone.  Differences from the reference that are deliberate: top-k accuracy is computed on the
+device (no ``.cpu().numpy()`` sync per iteration, heads/base.py:90) and ``_parse_losses`` reduces the
+log scalars in ONE all-reduce instead of four (recognizers/base.py:237-242).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import HEADS, LOSSES, RECOGNIZERS, Registry, build_backbone, build_head, build_loss
+
+MODULE_HOOKS = Registry("module_hooks")
+
+
+def top_k_accuracy(scores, labels, topk=(1,)):
+    """Reference semantics (accuracy.py:90-109): numpy argsort tie order."""
+    res = []
+    labels = np.array(labels)[:, np.newaxis]
+    for k in topk:
+        max_k_preds = np.argsort(scores, axis=1)[:, -k:][:, ::-1]
+        match_array = np.logical_or.reduce(max_k_preds == labels, axis=1)
+        res.append(match_array.sum() / match_array.shape[0])
+    return res
+
+
+def top_k_accuracy_device(cls_score: torch.Tensor, labels: torch.Tensor, topk=(1, 5)):
+    """Same quantity without leaving the GPU.  A label is in the top k iff fewer than k classes score
+    strictly higher, or tie and come later in numpy's stable ascending argsort (= larger index)."""
+    s = cls_score.detach().float()
+    tgt = s.gather(1, labels.view(-1, 1))
+    idx = torch.arange(s.shape[1], device=s.device).view(1, -1)
+    ahead = (s > tgt) | ((s == tgt) & (idx > labels.view(-1, 1)))
+    rank = ahead.sum(1)
+    return [(rank < min(k, s.shape[1])).float().mean() for k in topk]
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, loss_weight=1.0, class_weight=None):
+        super().__init__()
+        self.loss_weight = loss_weight
+        self.class_weight = None if class_weight is None else torch.Tensor(class_weight)
+
+    def _forward(self, cls_score, label, **kwargs):
+        if cls_score.size() == label.size():
+            assert cls_score.dim() == 2, 'Only support 2-dim soft label'
+            assert len(kwargs) == 0, f'For now, no extra args are supported for soft label, but get {kwargs}'
+            lsm = F.log_softmax(cls_score, 1)
+            if self.class_weight is not None:
+                self.class_weight = self.class_weight.to(cls_score.device)
+                lsm = lsm * self.class_weight.unsqueeze(0)
+            loss_cls = -(label * lsm).sum(1)
+            if self.class_weight is not None:
+                return loss_cls.sum() / torch.sum(self.class_weight.unsqueeze(0) * label)
+            return loss_cls.mean()
+        if self.class_weight is not None:
+            assert 'weight' not in kwargs, "The key 'weight' already exists."
+            kwargs['weight'] = self.class_weight.to(cls_score.device)
+        return F.cross_entropy(cls_score, label, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        return self._forward(*args, **kwargs) * self.loss_weight
+
+
+@HEADS.register_module()
+class I3DHead(nn.Module):
+    """avg-pool over (T,H,W) -> dropout -> fc (i3d_head.py:53-73)."""
+
+    def __init__(self, num_classes, in_channels, loss_cls=dict(type='CrossEntropyLoss'), spatial_type='avg',
+                 dropout_ratio=0.5, init_std=0.01, multi_class=False, label_smooth_eps=0.0, **kwargs):
+        super().__init__()
+        self.num_classes, self.in_channels = num_classes, in_channels
+        self.loss_cls = build_loss(loss_cls)
+        self.multi_class, self.label_smooth_eps = multi_class, label_smooth_eps
+        self.spatial_type, self.dropout_ratio, self.init_std = spatial_type, dropout_ratio, init_std
+        self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
+        self.fc_cls = nn.Linear(in_channels, num_classes)
+        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1)) if spatial_type == 'avg' else None
+
+    def init_weights(self):
+        nn.init.normal_(self.fc_cls.weight, 0, self.init_std)   # mmcv normal_init
+        nn.init.constant_(self.fc_cls.bias, 0)
+
+    def forward(self, x):
+        if self.avg_pool is not None:
+            x = self.avg_pool(x)
+        if self.dropout is not None:
+            x = self.dropout(x)
+        return self.fc_cls(x.view(x.shape[0], -1))
+
+    def loss(self, cls_score, labels, **kwargs):
+        """heads/base.py:68-108."""
+        losses = dict()
+        if labels.shape == torch.Size([]):
+            labels = labels.unsqueeze(0)
+        elif labels.dim() == 1 and labels.size()[0] == self.num_classes and cls_score.size()[0] == 1:
+            labels = labels.unsqueeze(0)
+        if not self.multi_class and cls_score.size() != labels.size():
+            top1, top5 = top_k_accuracy_device(cls_score, labels, (1, 5))
+            losses['top1_acc'], losses['top5_acc'] = top1, top5
+        elif self.multi_class and self.label_smooth_eps != 0:
+            labels = (1 - self.label_smooth_eps) * labels + self.label_smooth_eps / self.num_classes
+        loss_cls = self.loss_cls(cls_score, labels, **kwargs)
+        if isinstance(loss_cls, dict):
+            losses.update(loss_cls)
+        else:
+            losses['loss_cls'] = loss_cls
+        return losses
+
+
+@RECOGNIZERS.register_module()
+class Recognizer3D(nn.Module):
+    """3D recognizer framework for the AIM path (recognizer3d.py + recognizers/base.py)."""
+
+    def __init__(self, backbone, cls_head=None, neck=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        if neck is not None:
+            raise NotImplementedError("necks are outside the AIM ViT-CLIP path")
+        self.backbone_from = 'mmaction2'
+        self.backbone = build_backbone(backbone)
+        self.cls_head = build_head(cls_head) if cls_head else None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.aux_info = list(train_cfg['aux_info']) if train_cfg is not None and 'aux_info' in train_cfg else []
+        self.max_testing_views = None
+        if test_cfg is not None and 'max_testing_views' in test_cfg:
+            self.max_testing_views = test_cfg['max_testing_views']
+            assert isinstance(self.max_testing_views, int)
+        self.feature_extraction = bool(test_cfg and test_cfg.get('feature_extraction', False))
+        self.blending = None
+        self.init_weights()
+        self.fp16_enabled = False
+
+    with_neck = False
+
+    @property
+    def with_cls_head(self):
+        return self.cls_head is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.with_cls_head:
+            self.cls_head.init_weights()
+
+    def extract_feat(self, imgs):
+        return self.backbone(imgs)
+
+    def average_clip(self, cls_score, num_segs=1):
+        """recognizers/base.py:160-194."""
+        if 'average_clips' not in self.test_cfg.keys():
+            raise KeyError('"average_clips" must defined in test_cfg\'s keys')
+        average_clips = self.test_cfg['average_clips']
+        if average_clips not in ['score', 'prob', None]:
+            raise ValueError(f'{average_clips} is not supported. Currently supported ones are ["score", "prob", None]')
+        if average_clips is None:
+            return cls_score
+        batch_size = cls_score.shape[0]
+        cls_score = cls_score.view(batch_size // num_segs, num_segs, -1)
+        if average_clips == 'prob':
+            return F.softmax(cls_score, dim=2).mean(dim=1)
+        return cls_score.mean(dim=1)
+
+    def forward_train(self, imgs, labels, **kwargs):
+        assert self.with_cls_head
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])
+        x = self.extract_feat(imgs)
+        cls_score = self.cls_head(x)
+        gt_labels = labels.squeeze()
+        return dict(self.cls_head.loss(cls_score, gt_labels, **kwargs))
+
+    def _do_test(self, imgs):
+        batches, num_segs = imgs.shape[0], imgs.shape[1]
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])
+        if self.max_testing_views is not None:
+            total_views = imgs.shape[0]
+            assert num_segs == total_views, 'max_testing_views is only compatible with batch_size == 1'
+            feats = [self.extract_feat(imgs[p:p + self.max_testing_views])
+                     for p in range(0, total_views, self.max_testing_views)]
+            feat = torch.cat(feats)
+        else:
+            feat = self.extract_feat(imgs)
+        if self.feature_extraction:
+            feat = F.adaptive_avg_pool3d(feat, 1).reshape((batches, num_segs, -1))
+            return feat.mean(axis=1)
+        assert self.with_cls_head
+        return self.average_clip(self.cls_head(feat), num_segs)
+
+    def forward_test(self, imgs):
+        return self._do_test(imgs).cpu().numpy()
+
+    def forward_dummy(self, imgs, softmax=False):
+        assert self.with_cls_head
+        imgs = imgs.reshape((-1,) + imgs.shape[2:])
+        outs = self.cls_head(self.extract_feat(imgs))
+        if softmax:
+            outs = F.softmax(outs, dim=-1)
+        return (outs,)
+
+    def forward_gradcam(self, imgs):
+        return self._do_test(imgs)
+
+    @staticmethod
+    def _parse_losses(losses):
+        """recognizers/base.py:211-244, with the per-variable all-reduces coalesced into one."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        packed = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(packed.div_(dist.get_world_size()))
+        for (k, _), v in zip(list(log_vars.items()), packed.tolist()):
+            log_vars[k] = v
+        return loss, log_vars
+
+    def forward(self, imgs, label=None, return_loss=True, **kwargs):
+        if kwargs.get('gradcam', False):
+            del kwargs['gradcam']
+            return self.forward_gradcam(imgs, **kwargs)
+        if return_loss:
+            if label is None:
+                raise ValueError('Label should not be None.')
+            return self.forward_train(imgs, label, **kwargs)
+        return self.forward_test(imgs, **kwargs)
+
+    def train_step(self, data_batch, optimizer=None, **kwargs):
+        imgs, label = data_batch['imgs'], data_batch['label']
+        aux = {k: data_batch[k] for k in self.aux_info}
+        losses = self(imgs, label, return_loss=True, **aux)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(next(iter(data_batch.values()))))
+
+    val_step = train_step
+
+
+@MODULE_HOOKS.register_module()
+class GPUNormalize:
+    """uint8 -> (x - mean) / std on the device (module_hooks.py:35-87).  On this package's ``ViT_CLIP``
+    the normalisation is fused into the patch-embedding gather (``aim_patchify``) instead of
+    materialising a float copy of the clip."""
+
+    def __init__(self, input_format, mean, std):
+        if input_format not in ['NCTHW', 'NCHW', 'NCHW_Flow', 'NPTCHW']:
+            raise ValueError(f'The input format {input_format} is invalid.')
+        self.input_format = input_format
+        self.mean, self.std = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
+        shape = {'NCTHW': (1, -1, 1, 1, 1), 'NCHW': (1, -1, 1, 1), 'NCHW_Flow': (1, -1, 1, 1),
+                 'NPTCHW': (1, 1, 1, -1, 1, 1)}[input_format]
+        self._mean, self._std = self.mean.view(shape), self.std.view(shape)
+
+    def hook_func(self):
+        def normalize_hook(module, input):
+            x = input[0]
+            assert x.dtype == torch.uint8, (
+                f'The previous augmentation should use uint8 data type to speed up computation, but get {x.dtype}')
+            from .backbone import ViT_CLIP
+            if isinstance(module, ViT_CLIP) and self.input_format == 'NCTHW':
+                module._norm_mean = self.mean.to(x.device)
+                module._norm_std = self.std.to(x.device)
+                return input          # uint8 goes straight into the fused kernel
+            with torch.no_grad():
+                x = x.float().sub_(self._mean.to(x.device)).div_(self._std.to(x.device))
+            return (x, *input[1:])
+        return normalize_hook
+
+
+def register_module_hooks(Module, module_hooks_list):
+    """module_hooks.py:8-32."""
+    handles = []
+    for module_hook_cfg in module_hooks_list:
+        cfg = dict(module_hook_cfg)
+        hooked_module_name = cfg.pop('hooked_module', 'backbone')
+        hook_pos = cfg.pop('hook_pos', 'forward_pre')
+        module_hook = MODULE_HOOKS.build(cfg)
+        hooked_module = getattr(Module, hooked_module_name)
+        if hook_pos == 'forward_pre':
+            handle = hooked_module.register_forward_pre_hook(module_hook.hook_func())
+        elif hook_pos == 'forward':
+            handle = hooked_module.register_forward_hook(module_hook.hook_func())
+        elif hook_pos == 'backward':
+            handle = hooked_module.register_backward_hook(module_hook.hook_func())
+        else:
+            raise ValueError(f'hook_pos must be `forward_pre`, `forward` or `backward`, but get {hook_pos}')
+        handles.append(handle)
+    return handles

@@ -132,7 +132,7 @@ int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* do
  *            partials [BT, ntiles, 2];  cw[bt] = sum_i exp(q_i . kx[bt] / 8) is computed here.
  *   Both sums share one max shift (identical ratio, no overflow).  lam [BT] f32; one_minus [BT].
  * ------------------------------------------------------------------------------------------ */
-int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, const float* partials, int ntiles,
+int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* partials, int ntiles,
                float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -314,7 +314,8 @@ def _lin(a: Tensor, w: Tensor, b: Optional[Tensor], rnd: Rounding) -> Tensor:
 
 
 def emu_adapter(x: Tensor, st: State, pre: str, rnd: Rounding) -> Tensor:
-    h = rnd(F.gelu(_lin(x, st[pre + ".D_fc1.weight"], st[pre + ".D_fc1.bias"], rnd)))
+    a = rnd(_lin(x, st[pre + ".D_fc1.weight"], st[pre + ".D_fc1.bias"], rnd))   # stored pre-activation
+    h = rnd(F.gelu(a))
     return _lin(h, st[pre + ".D_fc2.weight"], st[pre + ".D_fc2.bias"], rnd)
 
 

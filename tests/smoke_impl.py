@@ -1,0 +1,30 @@
+"""smoke(): one tiny forward+backward of the HIP backbone on cuda:0, checked against the CPU oracle."""
+import torch
+
+from oracle import vit_clip_oracle as O
+
+
+def run_smoke():
+    import aim_amd
+    T, D, L, H = 2, 128, 2, 2
+    m = aim_amd.ViT_CLIP(32, T, 16, D, L, H, 0.0)
+    m.init_weights()
+    st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, L), seed=11)
+    m.load_state_dict(st, strict=True)
+    m = m.to("cuda:0").eval()
+    imgs = torch.randn((2, 3, T, 32, 32), generator=torch.Generator().manual_seed(5))
+    g = torch.randn((2, D, T, 1, 1), generator=torch.Generator().manual_seed(6))
+    y = m(imgs.to("cuda:0"))
+    y.backward(g.to("cuda:0"))
+    names = O.trainable_names(st)
+    for n in names:
+        st[n] = st[n].detach().requires_grad_(True)
+    y_ref = O.emu_backbone(imgs, st, H, rnd=O.BF16)
+    grads = torch.autograd.grad(y_ref, [st[n] for n in names], g)
+    err = (y.detach().cpu() - y_ref.detach()).abs().max().item()
+    assert err < 4e-3, f"smoke forward mismatch {err}"
+    got = dict(m.named_parameters())
+    for n, gr in zip(names, grads):
+        e = ((got[n].grad.cpu() - gr).norm() / (gr.norm() + 1e-30)).item()
+        assert e < 6e-2, f"smoke grad mismatch {n}: {e}"
+    print(f"smoke ok: fwd max err {err:.2e}")
