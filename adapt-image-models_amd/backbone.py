@@ -293,7 +293,7 @@ class _BackboneFn(torch.autograd.Function):
         BT, M = B * T, B * T * N
         dev = imgs.device
         temporal, lnp_w, lnp_b = params[0], params[1], params[2]
-        need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in params)
+        need_grad = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
         frozen = model._frozen_operands()
         adp = []
         for i in range(L):

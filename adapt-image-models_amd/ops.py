@@ -21,6 +21,35 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the large GEMM launches (bench.py roofline leg).  Events are
+    recorded on the stream the kernel is launched on; durations are read after the timed region."""
+
+    def __init__(self, min_flops: float = 1e10):
+        self.min_flops = min_flops
+        self.enabled = False
+        self.records = []          # (epi, flops, start_event, end_event)
+
+    def start(self):
+        self.records, self.enabled = [], True
+
+    def stop(self):
+        self.enabled = False
+
+    def summary(self):
+        """-> {epi: dict(launches, flops, ms)} ; call after torch.cuda.synchronize()."""
+        out = {}
+        for epi, fl, e0, e1 in self.records:
+            d = out.setdefault(epi, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+GEMM_TIMER = KernelTimer()
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -71,7 +100,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
         _chk(out, BF16, "out")
     else:
         _chk(out, F32, "out")
+    timed = GEMM_TIMER.enabled and 2.0 * g.M * g.N * g.K * batch >= GEMM_TIMER.min_flops
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.aim_gemm_bf16(byref(g), epi, batch, _stream()), "aim_gemm_bf16")
+    if timed:
+        e1.record()
+        GEMM_TIMER.records.append((epi, 2.0 * g.M * g.N * g.K * batch, e0, e1))
     return out
 
 

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/s of the AIM ViT-CLIP+Adapter training step (fwd + bwd + AdamW) on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0 prints ONE
+JSON line.  Workload = BASELINE.json configs[1]: ViT-B/16 + AIM, 8 frames 224^2, bf16 operands / fp32
+accumulate, 64 clips per GPU, synthetic N(0,1) clips and U{0..399} labels, random-init weights
+(pretrained=None, D_fc2 ~ N(0, .02) so the adapters are live), drop_path 0.2 and head dropout 0.5 ON.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6        # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md: ~2.5 PF)
+GF_PER_CLIP = {"fwd": 293.1, "bwd": 314.0}   # SURVEY section 8(d), ViT-B/16 T=8, algorithmic
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(frames, dev):
+    import aim_amd
+    cfg = dict(
+        type='Recognizer3D',
+        backbone=dict(type='ViT_CLIP', input_resolution=224, patch_size=16, num_frames=frames, width=768, layers=12,
+                      heads=12, drop_path_rate=0.2, adapter_scale=0.5, pretrained=None),
+        cls_head=dict(type='I3DHead', in_channels=768, num_classes=400, spatial_type='avg', dropout_ratio=0.5),
+        test_cfg=dict(average_clips='prob'))
+    torch.manual_seed(0)
+    model = aim_amd.build_model(cfg)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "D_fc2" in n:
+                p.normal_(0, 0.02)
+    return model.to(dev).train()
+
+
+def cpu_baseline(frames):
+    """The CPU oracle (literal restatement of the reference forward, pinned by tests/golden) timed on the
+    host cores: 1 clip, fp32, fwd + bwd of backbone + head + CE.  Bounded sample (~10-30 s)."""
+    from oracle import vit_clip_oracle as O
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    st = O.synth_state_dict(O.backbone_param_shapes(224, frames, 16, 768, 12), seed=0)
+    names = O.trainable_names(st)
+    for n in names:
+        st[n].requires_grad_(True)
+    fc_w = (torch.randn(400, 768) * 0.01).requires_grad_(True)
+    fc_b = torch.zeros(400, requires_grad=True)
+    imgs = torch.randn(1, 3, frames, 224, 224)
+    label = torch.tensor([7])
+
+    def step():
+        y = O.ref_backbone(imgs, st, 12, frames)
+        loss = O.ref_cross_entropy(O.ref_i3d_head(y, fc_w, fc_b), label)
+        torch.autograd.grad(loss, [st[n] for n in names] + [fc_w, fc_b])
+
+    step()
+    times = []
+    t_end = time.time() + 20.0
+    while len(times) < 5 or (time.time() < t_end and len(times) < 8):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    model_name = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=round(1.0 / med, 4), unit="clips/s", cores=threads, kind="port",
+                sample=f"1 clip x {len(times)} steps (median), ViT-B/16 T={frames} fp32 fwd+bwd+head on {model_name}")
+
+
+def main():
+    args = parse()
+    from aim_amd.dist import FlatGradReducer, build_optimizer, init_distributed
+    from aim_amd import ops
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = build_model(args.frames, dev)
+    reducer = FlatGradReducer(model.parameters())
+    reducer.broadcast_params(model)
+    opt = build_optimizer(model, dict(
+        type='AdamW', lr=3e-4, betas=(0.9, 0.999), weight_decay=0.05,
+        paramwise_cfg=dict(custom_keys={k: dict(decay_mult=0.) for k in
+                                        ('class_embedding', 'positional_embedding', 'ln_1', 'ln_2', 'ln_pre', 'ln_post')})))
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B = args.batch
+    imgs = torch.randn((B, 1, 3, args.frames, 224, 224), generator=g).to(dev)      # resident in HBM
+    label = torch.randint(0, 400, (B, 1), generator=g).to(dev)
+
+    def step():
+        reducer.zero_grad()
+        losses = model(imgs, label, return_loss=True)
+        loss = losses["loss_cls"]
+        loss.backward()
+        reducer.all_reduce()
+        opt.step()
+        return losses
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timing = (not args.no_kernel_timing) and rank == 0
+    if timing:
+        ops.GEMM_TIMER.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.GEMM_TIMER.stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(losses["loss_cls"])
+
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips / dt
+        gf = GF_PER_CLIP["fwd"] + GF_PER_CLIP["bwd"]
+        out = {
+            "metric": "clips/sec (8-frame 224^2 ViT-B/16 AIM fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ViT-B/16 + AIM adapters, 8 frames 224^2, 64 clips/GPU, "
+                                   "K400-shaped synthetic clips (400 random labels), fwd+bwd+AdamW",
+                       "global_batch": B * world, "frames": args.frames, "parallelism": f"dp{world}",
+                       "drop_path_rate": 0.2, "head_dropout": 0.5},
+            "mfma_frac_whole_step": round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4) if args.frames == 8 else None,
+            "loss": round(loss_val, 4),
+        }
+        roof = None
+        if timing:
+            names = {0: "gemm_kernel<EPI_BF16>", 1: "gemm_kernel<EPI_ACT>", 2: "gemm_kernel<EPI_DACT>",
+                     3: "gemm_kernel<EPI_F32>", 4: "gemm_kernel<EPI_EXPSUM>"}
+            summ = ops.GEMM_TIMER.summary()
+            if summ:
+                tot_ms = sum(d["ms"] for d in summ.values())
+                tot_fl = sum(d["flops"] for d in summ.values())
+                dom = max(summ, key=lambda k: summ[k]["ms"])
+                d = summ[dom]
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": d["launches"] / args.steps,
+                        "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                        "flops_per_launch": d["flops"] / d["launches"],
+                        "all_large_gemms": {"TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                            "ms_per_step": round(tot_ms / args.steps, 3),
+                                            "share_of_step": round(tot_ms / (dt * 1e3), 3)},
+                        "per_variant": {names[k]: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                                   "avg_ms": round(v["ms"] / v["launches"], 4),
+                                                   "launches_per_step": v["launches"] / args.steps}
+                                        for k, v in sorted(summ.items())}}
+        out["roofline"] = roof
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
