@@ -8,3 +8,4 @@ enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, 
 enum { ACT_QGELU = AIM_ACT_QGELU, ACT_GELU = AIM_ACT_GELU };
 
 int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st);
+int aim_gemm256_launch(const GemmArgs& g, int epi, hipStream_t st);

@@ -60,6 +60,7 @@ __device__ __forceinline__ f32x4 embed_value(const bf16_t* tok, const float* cls
     return v;
 }
 
+template <int NC>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict__ tok, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, const float* __restrict__ tmp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -70,10 +71,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict_
     if (row >= (long long)B * T * N) return;
     const long long bt = row / N;
     const int n = (int)(row - bt * N), t = (int)(bt % T), nch = D >> 2;
-    f32x4 v[MAXC];
+    f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             v[c] = embed_value(tok, cls, pos, tmp, bt, n, t, N - 1, D, ch * 4);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict_
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
 #pragma unroll
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict_
         rstd[row] = rs;
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict_
 
 // grid (T, chunks): every wave walks rows (b, n) of frame-time t, accumulates ln_pre's input gradient
 // in registers and adds it into dtemporal[t] once at the end.
+template <int NC>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ tok,
                                                         const float* __restrict__ cls, const float* __restrict__ pos,
                                                         const float* __restrict__ tmp, const float* __restrict__ gamma,
@@ -120,18 +122,18 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ dtemporal, int B, int T, int N, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x, nch = D >> 2;
-    f32x4 acc[MAXC];
+    f32x4 acc[NC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int total = B * N;
     for (int r = blockIdx.y * 4 + wave; r < total; r += gridDim.y * 4) {
         const int b = r / N, n = r - b * N;
         const long long bt = (long long)b * T + t, row = bt * N + n;
         const float mu = mean[row], rs = rstd[row];
-        f32x4 g[MAXC], xh[MAXC];
+        f32x4 g[NC], xh[NC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int ch = lane + c * 64;
             if (ch < nch) {
                 const f32x4 v = embed_value(tok, cls, pos, tmp, bt, n, t, N - 1, D, ch * 4);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         }
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int ch = lane + c * 64;
             if (ch < nch) {
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
 #pragma unroll
@@ -197,6 +199,34 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     atomicAdd(out + c, acc);
 }
 
+// 8 columns per thread (16-byte loads); threads = (C/8 column groups) x (row slots); rows strided by slots
+__global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ af,
+                                                      const float* __restrict__ at, int ntok, float* __restrict__ out,
+                                                      int M, int C, int rows_per_block) {
+    const int cg = C >> 3;
+    const int nrs = 256 / cg > 0 ? 256 / cg : 1;
+    const int t = threadIdx.x;
+    const int col = t % cg;   // column group
+    const int rslot = t / cg;
+    if (rslot >= nrs) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rslot; r < r1; r += nrs) {
+        float rs = 1.f;
+        if (af || at) {
+            const int f = r / ntok, tk = r - f * ntok;
+            if (af) rs *= af[f];
+            if (at) rs *= at[tk];
+        }
+        const bf16x8 v = *(const bf16x8*)(X + (long long)r * ldx + col * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += rs * (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + col * 8 + e, acc[e]);
+}
+
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -233,7 +263,46 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
     if (yf) yf[i] = v;
 }
 
+// AdamW (decoupled weight decay) on flat fp32 buffers, torch.optim.AdamW semantics.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 pp = *(f32x4*)(p + i), mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+        const f32x4 gg = *(const f32x4*)(g + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pp[e] *= 1.0f - lr * wd;
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gg[e];
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+            pp[e] -= (lr / bc1) * mm[e] / (sqrtf(vv[e]) / bc2s + eps);
+        }
+        *(f32x4*)(p + i) = pp;
+        *(f32x4*)(m + i) = mm;
+        *(f32x4*)(v + i) = vv;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            float pp = p[j] * (1.0f - lr * wd);
+            const float mm = b1 * m[j] + (1.0f - b1) * g[j], vv = b2 * v[j] + (1.0f - b2) * g[j] * g[j];
+            pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2s + eps);
+            p[j] = pp; m[j] = mm; v[j] = vv;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int aim_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, void* stream) {
+    AIM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    AIM_CHECK_LAUNCH("aim_adamw_flat");
+    return 0;
+}
 
 extern "C" int aim_patchify(const void* imgs, int in_dtype, const float* mean3, const float* std3, aim_bf16* A, int B,
                             int T, int H, int W, int p, int Kp, void* stream) {
@@ -263,8 +332,12 @@ extern "C" int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* 
     AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_ln: bad shape N=%d D=%d", N, D);
     AIM_CHECK_ARG(tok && cls && pos && temporal && gamma && beta && x && mean && rstd, "embed_ln: null pointer");
     const long long rows = (long long)B * T * N;
-    hipLaunchKernelGGL(embed_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)tok, cls, pos, temporal, gamma, beta, x, mean, rstd, B, T, N, D, eps);
+#define AIM_EL(NC)                                                                                                 \
+    hipLaunchKernelGGL(embed_ln_kernel<NC>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,      \
+                       (const bf16_t*)tok, cls, pos, temporal, gamma, beta, x, mean, rstd, B, T, N, D, eps)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_EL(1); else if (nc == 2) AIM_EL(2); else if (nc == 3) AIM_EL(3); else if (nc == 4) AIM_EL(4); else AIM_EL(8);
+#undef AIM_EL
     AIM_CHECK_LAUNCH("aim_embed_ln");
     return 0;
 }
@@ -275,9 +348,14 @@ extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* 
     AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_bwd: bad shape N=%d D=%d", N, D);
     AIM_CHECK_ARG(dx && tok && cls && pos && temporal && gamma && mean && rstd && dtemporal, "embed_bwd: null pointer");
     int chunks = (B * N + 3) / 4;
-    if (chunks > 128) chunks = 128;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, chunks), dim3(256), 0, (hipStream_t)stream, dx, (const bf16_t*)tok, cls,
-                       pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D);
+    const int want = (2048 + T - 1) / T;
+    if (chunks > want) chunks = want;
+#define AIM_EB(NC)                                                                                                 \
+    hipLaunchKernelGGL(embed_bwd_kernel<NC>, dim3(T, chunks), dim3(256), 0, (hipStream_t)stream, dx, (const bf16_t*)tok, \
+                       cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_EB(1); else if (nc == 2) AIM_EB(2); else if (nc == 3) AIM_EB(3); else if (nc == 4) AIM_EB(4); else AIM_EB(8);
+#undef AIM_EB
     AIM_CHECK_LAUNCH("aim_embed_bwd");
     return 0;
 }
@@ -293,6 +371,14 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
                                int M, int C, void* stream) {
     AIM_CHECK_ARG(M > 0 && C > 0 && X && out, "colsum: bad arguments");
     if (af || at) AIM_CHECK_ARG(ntok > 0, "colsum: ntok required with row factors");
+    if ((C % 8) == 0 && C <= 2048 && (ldx % 8) == 0) {
+        int rpb8 = (M + 1023) / 1024;
+        if (rpb8 < 32) rpb8 = 32;
+        hipLaunchKernelGGL(colsum8_kernel, dim3(1, (M + rpb8 - 1) / rpb8), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)X, ldx, af, at, ntok, out, M, C, rpb8);
+        AIM_CHECK_LAUNCH("aim_colsum_bf16");
+        return 0;
+    }
     int rpb = (M + 511) / 512;
     if (rpb < 64) rpb = 64;
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,

@@ -15,6 +15,8 @@
 // lane owns 4 consecutive output columns of one row: 8-byte bf16 / 16-byte f32 stores.
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -146,55 +148,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + frow;
             if (m >= g.M) continue;
-            float rs = 1.0f, vs = 0.0f;
-            int frame = 0;
-            if (g.af || g.at || g.vec) {
-                frame = m / g.ntok;
-                const int tok = m - frame * g.ntok;
-                if (g.af) rs *= g.af[frame];
-                if (g.at) rs *= g.at[tok];
-                if (g.vec) vs = g.bt ? g.bt[tok] : 1.0f;
-            }
+            const RowFactors rf = row_factors(g, m);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + fq * 4;
                 if (n >= g.N) continue;
-                f32x4 v = acc[i][j];
-                if (g.bias) {
-                    const f32x4 b = *(const f32x4*)(g.bias + n);
-                    if (EPI == EPI_F32 && g.rs_bias_only) v += rs * b; else v += b;
-                }
-                if constexpr (EPI == EPI_BF16) {
-                    v *= rs;
-                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_ACT) {
-                    bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
-                    *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
-                    float p0 = (float)pre[0], p1 = (float)pre[1], p2 = (float)pre[2], p3 = (float)pre[3];
-                    bf16x4 post = (g.act == ACT_QGELU)
-                                      ? pack4(rs * quick_gelu(p0), rs * quick_gelu(p1), rs * quick_gelu(p2), rs * quick_gelu(p3))
-                                      : pack4(rs * gelu_erf(p0), rs * gelu_erf(p1), rs * gelu_erf(p2), rs * gelu_erf(p3));
-                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = post;
-                } else if constexpr (EPI == EPI_DACT) {
-                    const bf16x4 pre = *(const bf16x4*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
-                    float d[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        d[e] = (g.act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
-                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) =
-                        pack4(rs * v[0] * d[0], rs * v[1] * d[1], rs * v[2] * d[2], rs * v[3] * d[3]);
-                } else if constexpr (EPI == EPI_F32) {
-                    if (!g.rs_bias_only) v *= rs;
-                    if (g.vec) {
-                        const f32x4 w = *(const f32x4*)(g.vec + (long long)frame * g.ldv + n);
-                        v += vs * w;
-                    }
-                    if (g.resid) {
-                        const f32x4 r = *(const f32x4*)(g.resid + (long long)m * g.ldr + n);
-                        v += r;
-                    }
-                    *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
-                }
+                store_frag<EPI>(g, acc[i][j], m, n, rf);
             }
         }
     }
@@ -218,6 +177,10 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     AIM_CHECK_ARG(g.A && g.W && g.out, "gemm: null operand");
     AIM_CHECK_ARG((long long)128 * g.lda * 2 < 0x7fffffffLL && (long long)128 * g.ldw * 2 < 0x7fffffffLL, "gemm: leading dimension too large");
     if (g.af || g.at || g.vec) AIM_CHECK_ARG(g.ntok > 0, "gemm: ntok required with row factors");
+    // large-M problems run on the 256x256 pipelined kernel (gemm256.hip); AIM_GEMM_TILE=128 forces v1
+    static const int force128 = [] { const char* e = getenv("AIM_GEMM_TILE"); return e && atoi(e) == 128; }();
+    if (!force128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 128)
+        return aim_gemm256_launch(g, epi, st);
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(g, batch, st);
         case EPI_ACT:

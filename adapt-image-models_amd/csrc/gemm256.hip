@@ -1,0 +1,269 @@
+// bf16 MFMA GEMM, 256x256x64 block tile, 8 waves, software-pipelined LDS-DMA staging with counted
+// vmcnt.  gfx950 only.  Same contract and epilogues as gemm.hip (C = A W^T, both K-contiguous); this is
+// the kernel the large-M GEMMs of the AIM block run on (QKV / out_proj / c_fc / c_proj / adapter
+// projections and their dgrads: reference vit_clip.py:93-97,132-138,157,286 and autograd).
+//
+// Geometry: 8 waves as 2(M) x 4(N); a wave owns a 128x64 output tile = 8x4 MFMA 16x16x32 tiles
+// (128 accumulator VGPRs).  LDS = 2 K-tile buffers x {A_lo, A_hi, B_lo, B_hi} half-tiles of
+// 128 rows x 64 k (16 KiB each, XOR-swizzled image of aim_common.h) = 128 KiB, one block per CU.
+//
+// Schedule: one loop iteration = 2 K-tiles (E = even buffer, O = odd buffer) = 8 phases.  Each phase
+//   { optional fragment ds_reads ; stage ONE half-tile (2 buffer_load...lds per wave) ;
+//     [phases 4, 8: s_waitcnt vmcnt(6)] ; s_barrier ; s_waitcnt lgkmcnt(0) ; 16 MFMA ; s_barrier }.
+// A wave reads all its B fragments and the first 64-row A sub-block in phase 1 (5), the second A
+// sub-block in phase 3 (7), so a buffer's B halves are free after phase 1 (5) and its A halves after
+// phase 3 (7).  Staging order  ph1 O.A_hi(t+1) | ph2 E.B_lo(t+2) | ph3 E.B_hi | ph4 E.A_lo | ph5 E.A_hi |
+// ph6 O.B_lo(t+3) | ph7 O.B_hi | ph8 O.A_lo  keeps three half-tiles (6 loads per wave) in flight across
+// every wait: vmcnt(6) at phase 4 retires tile t+1 (read from phase 5 on), at phase 8 tile t+2 (read
+// from the next phase 1 on).  RAW: every read of a staged half-tile is at least one barrier after the
+// counted wait that retired it.  WAR: a half-tile is re-staged one phase after its last ds_read, whose
+// lgkmcnt(0) precedes that phase's closing barrier.  Tiles past K are staged with out-of-range
+// offsets (zero fill, still counted by vmcnt) so the counts are uniform.
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int HT = 128 * 64 * 2;        // half-tile bytes
+constexpr int BUF = 4 * HT;             // one K-tile buffer: A_lo, A_hi, B_lo, B_hi
+constexpr int OFF_A = 0, OFF_B = 2 * HT;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
+
+    const int tiles_n = (g.N + 255) >> 8;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const bf16_t* Ab = (const bf16_t*)g.A + (long long)m0 * g.lda;
+    const bf16_t* Wb = (const bf16_t*)g.W + (long long)n0 * g.ldw;
+    const int rowsA = g.M - m0, rowsW = g.N - n0;
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab, ((long long)(rowsA - 1) * g.lda + g.K) * 2);
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(Wb, ((long long)(rowsW - 1) * g.ldw + g.K) * 2);
+
+    // staging constants: half-tile = 16 pieces of 8 rows; wave stages pieces 2*wave, 2*wave+1
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    unsigned voA[2][2], voW[2][2];   // [half][piece]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = h * 128 + (wave * 2 + j) * 8 + srow;
+            voA[h][j] = r < rowsA ? (unsigned)((r * g.lda + schunk * 8) * 2) : AIM_OOB;
+            voW[h][j] = r < rowsW ? (unsigned)((r * g.ldw + schunk * 8) * 2) : AIM_OOB;
+        }
+    const int nk = (g.K + 63) >> 6;
+
+    // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi
+    auto stage = [&](int buf, int which, int kt) {
+        const int k0 = kt * 64;
+        const bool kin = (k0 + schunk * 8) < g.K;
+        AIM_LDS char* dst = smem + buf * BUF + which * HT + wave * 2048;
+        const int h = which & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (which < 2) {
+                const unsigned v = (kin && voA[h][j] != AIM_OOB) ? voA[h][j] + (unsigned)(k0 * 2) : AIM_OOB;
+                stage_piece(rA, dst + j * 1024, v);
+            } else {
+                const unsigned v = (kin && voW[h][j] != AIM_OOB) ? voW[h][j] + (unsigned)(k0 * 2) : AIM_OOB;
+                stage_piece(rW, dst + j * 1024, v);
+            }
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], bfr[4][2];
+
+    auto read_b = [&](int buf) {
+        const AIM_LDS char* sB = smem + buf * BUF + OFF_B + (wn >> 1) * HT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = lds_read8(sB + swz_off((wn & 1) * 64 + j * 16 + frow, ks * 4 + fq));
+    };
+    auto read_a = [&](int buf, int sub) {
+        const AIM_LDS char* sA = smem + buf * BUF + OFF_A + wm * HT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = lds_read8(sA + swz_off(sub * 64 + i * 16 + frow, ks * 4 + fq));
+    };
+    // 16 MFMA: A sub-block `sub` (4 m-tiles) x B tiles {jb, jb+1} x 2 k-substeps
+    auto mma = [&](int sub, int jb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[sub * 4 + i][jb + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jb + j][ks], af[i][ks], acc[sub * 4 + i][jb + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define AIM_BAR() __builtin_amdgcn_s_barrier()
+#define AIM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define AIM_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+
+    // prologue: tile 0 complete, three half-tiles of tile 1 in flight
+    stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);
+    stage(1, 2, 1); stage(1, 3, 1); stage(1, 0, 1);
+    AIM_VM6();
+    AIM_BAR();
+
+    const int niter = (nk + 1) >> 1;
+    for (int it = 0; it < niter; ++it) {
+        const int te = 2 * it, to = te + 1;
+        const bool odd_live = to < nk;
+        // ---- even tile (buffer 0) ----
+        read_b(0); read_a(0, 0);
+        stage(1, 1, to);
+        AIM_BAR(); AIM_LGKM0();
+        mma(0, 0);
+        AIM_BAR();
+        // phase 2
+        stage(0, 2, te + 2);
+        AIM_BAR();
+        mma(0, 2);
+        AIM_BAR();
+        // phase 3
+        read_a(0, 1);
+        stage(0, 3, te + 2);
+        AIM_BAR(); AIM_LGKM0();
+        mma(1, 2);
+        AIM_BAR();
+        // phase 4
+        stage(0, 0, te + 2);
+        AIM_VM6();
+        AIM_BAR();
+        mma(1, 0);
+        AIM_BAR();
+        // ---- odd tile (buffer 1) ----
+        if (odd_live) { read_b(1); read_a(1, 0); }
+        stage(0, 1, te + 2);
+        AIM_BAR(); AIM_LGKM0();
+        if (odd_live) mma(0, 0);
+        AIM_BAR();
+        // phase 6
+        stage(1, 2, to + 2);
+        AIM_BAR();
+        if (odd_live) mma(0, 2);
+        AIM_BAR();
+        // phase 7
+        if (odd_live) read_a(1, 1);
+        stage(1, 3, to + 2);
+        AIM_BAR(); AIM_LGKM0();
+        if (odd_live) mma(1, 2);
+        AIM_BAR();
+        // phase 8
+        stage(1, 0, to + 2);
+        AIM_VM6();
+        AIM_BAR();
+        if (odd_live) mma(1, 0);
+        AIM_BAR();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
+
+    // ---- epilogue through LDS: re-tile each wave's 128x64 block so that a wave-instruction covers
+    // 4 rows x 64 consecutive columns (16 lanes x 4 columns per row): residual / aux loads and the
+    // output stores are then whole 128-256 B lines instead of 8-16 B fragments per lane.
+    AIM_BAR();                                    // every wave is done reading the K-loop images
+    {
+        constexpr int RS = 272;                   // padded row stride (64 f32 + 16 B)
+        AIM_LDS char* scr = smem + wave * (32 * RS);
+        const int rr = lane >> 4, cc = (lane & 15) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(AIM_LDS f32x4*)(scr + (ii * 16 + frow) * RS + (j * 16 + fq * 4) * 4) = acc[pass * 2 + ii][j];
+            if constexpr (EPI != EPI_BF16) {
+                FragIn fin[8];
+                const int n = n0 + wn * 64 + cc;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int m = m0 + wm * 128 + pass * 32 + t * 4 + rr;
+                    if (m < g.M && n < g.N) fin[t] = load_frag_in<EPI>(g, m, n);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int r = t * 4 + rr;
+                    const f32x4 v = *(const AIM_LDS f32x4*)(scr + r * RS + cc * 4);
+                    const int m = m0 + wm * 128 + pass * 32 + r;
+                    if (m < g.M && n < g.N) store_frag<EPI>(g, v, m, n, row_factors(g, m), fin[t]);
+                }
+            } else {
+                // bf16 outputs: 8 lanes x 8 columns per row, 8 rows per wave-instruction, 16-byte stores
+                const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+                const int n = n0 + wn * 64 + c8;
+                const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N &&
+                                  (EPI != EPI_ACT || (g.ldo2 % 8) == 0) && (EPI != EPI_DACT || (g.ldaux % 8) == 0);
+                bf16x8 aux8[4];
+                if constexpr (EPI == EPI_DACT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = m0 + wm * 128 + pass * 32 + t * 8 + r8;
+                        if (m < g.M && wide) aux8[t] = *(const bf16x8*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = t * 8 + r8;
+                    const f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r * RS + c8 * 4);
+                    const f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r * RS + c8 * 4 + 16);
+                    const int m = m0 + wm * 128 + pass * 32 + r;
+                    if (m >= g.M || n >= g.N) continue;
+                    const RowFactors rf = row_factors(g, m);
+                    if (wide) {
+                        store_frag8<EPI>(g, v0, v1, m, n, rf, aux8[t]);
+                    } else {   // ragged N / odd strides: 4-column form
+                        store_frag<EPI>(g, v0, m, n, rf);
+                        if (n + 4 < g.N) store_frag<EPI>(g, v1, m, n + 4, rf);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch256(const GemmArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        attr_set = true;
+    }
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles), dim3(512), 2 * BUF, st, g);
+    AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
+    return 0;
+}
+
+}  // namespace
+
+int aim_gemm256_launch(const GemmArgs& g, int epi, hipStream_t st) {
+    AIM_CHECK_ARG((long long)256 * g.lda * 2 < 0x7fffffffLL && (long long)256 * g.ldw * 2 < 0x7fffffffLL, "gemm256: leading dimension too large");
+    switch (epi) {
+        case EPI_BF16: return launch256<EPI_BF16>(g, st);
+        case EPI_ACT: return launch256<EPI_ACT>(g, st);
+        case EPI_DACT: return launch256<EPI_DACT>(g, st);
+        case EPI_F32: return launch256<EPI_F32>(g, st);
+    }
+    aim_set_error("gemm256: unsupported epilogue %d", epi);
+    return 1;
+}

@@ -1,0 +1,123 @@
+// Fused GEMM epilogues shared by the 128x128 and 256x256 kernels.  A lane owns, per 16x16 MFMA tile,
+// row m and the 4 consecutive columns n..n+3 (the MFMA is issued with the weight fragment first).
+#pragma once
+#include "aim_common.h"
+#include "aim_kernels_internal.h"
+
+struct RowFactors {
+    float rs, vs;
+    int frame;
+};
+
+__device__ __forceinline__ RowFactors row_factors(const GemmArgs& g, int m) {
+    RowFactors r{1.0f, 0.0f, 0};
+    if (g.af || g.at || g.vec) {
+        r.frame = m / g.ntok;
+        const int tok = m - r.frame * g.ntok;
+        if (g.af) r.rs *= g.af[r.frame];
+        if (g.at) r.rs *= g.at[tok];
+        if (g.vec) r.vs = g.bt ? g.bt[tok] : 1.0f;
+    }
+    return r;
+}
+
+// Epilogue inputs that come from memory, fetched ahead of the arithmetic so that a wave keeps many
+// loads in flight (resid may alias out, so the compiler cannot hoist these loads across stores itself).
+struct FragIn {
+    f32x4 resid;
+    bf16x4 aux;
+};
+
+template <int EPI>
+__device__ __forceinline__ FragIn load_frag_in(const GemmArgs& g, int m, int n) {
+    FragIn f;
+    f.resid = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_F32) {
+        if (g.resid) f.resid = *(const f32x4*)(g.resid + (long long)m * g.ldr + n);
+    }
+    if constexpr (EPI == EPI_DACT) f.aux = *(const bf16x4*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
+    return f;
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, int n, const RowFactors& rf,
+                                           const FragIn& fin) {
+    const float rs = rf.rs;
+    if (g.bias) {
+        const f32x4 b = *(const f32x4*)(g.bias + n);
+        if (EPI == EPI_F32 && g.rs_bias_only) v += rs * b; else v += b;
+    }
+    if constexpr (EPI == EPI_BF16) {
+        v *= rs;
+        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_ACT) {
+        const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
+        *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+        const float p0 = (float)pre[0], p1 = (float)pre[1], p2 = (float)pre[2], p3 = (float)pre[3];
+        const bf16x4 post = (g.act == ACT_QGELU)
+                                ? pack4(rs * quick_gelu(p0), rs * quick_gelu(p1), rs * quick_gelu(p2), rs * quick_gelu(p3))
+                                : pack4(rs * gelu_erf(p0), rs * gelu_erf(p1), rs * gelu_erf(p2), rs * gelu_erf(p3));
+        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = post;
+    } else if constexpr (EPI == EPI_DACT) {
+        const bf16x4 pre = fin.aux;
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            d[e] = (g.act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
+        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) =
+            pack4(rs * v[0] * d[0], rs * v[1] * d[1], rs * v[2] * d[2], rs * v[3] * d[3]);
+    } else if constexpr (EPI == EPI_F32) {
+        if (!g.rs_bias_only) v *= rs;
+        if (g.vec) {
+            const f32x4 w = *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
+            v += rf.vs * w;
+        }
+        v += fin.resid;
+        *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, int n, const RowFactors& rf) {
+    store_frag<EPI>(g, v, m, n, rf, load_frag_in<EPI>(g, m, n));
+}
+
+// 8-column form for the bf16-output epilogues: the lane owns columns n..n+7 of row m, so each output
+// row segment leaves as ONE 16-byte store (the 8-byte form is store-issue-bound).
+template <int EPI>
+__device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v1, int m, int n, const RowFactors& rf,
+                                            const bf16x8& aux8) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_ACT || EPI == EPI_DACT, "bf16-output epilogues only");
+    const float rs = rf.rs;
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (g.bias) {
+        const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+        }
+    }
+    bf16x8 o;
+    if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rs * v[e]);
+    } else if constexpr (EPI == EPI_ACT) {
+        bf16x8 pre;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[e] = (bf16_t)v[e];
+        *(bf16x8*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float p = (float)pre[e];
+            o[e] = (bf16_t)(rs * (g.act == ACT_QGELU ? quick_gelu(p) : gelu_erf(p)));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float p = (float)aux8[e];
+            o[e] = (bf16_t)(rs * v[e] * (g.act == ACT_QGELU ? quick_gelu_grad(p) : gelu_erf_grad(p)));
+        }
+    }
+    *(bf16x8*)((bf16_t*)g.out + (long long)m * g.ldo + n) = o;
+}

@@ -10,8 +10,9 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // float4 chunks per lane: D <= 8*4*64 = 2048
+constexpr int MAXC = 8;  // float4 chunks per lane: D <= 8*4*64 = 2048 (template NC = chunks actually used)
 
+template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16_t* __restrict__ yb, float* __restrict__ yf, long long ldy,
@@ -22,10 +23,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= rows) return;
     const int nch = D >> 2;
     const float* xr = x + (long long)row * ldx;
-    f32x4 v[MAXC];
+    f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             v[c] = *(const f32x4*)(xr + ch * 4);
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
 #pragma unroll
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (rstd) rstd[row] = rs;
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             const f32x4 g = *(const f32x4*)(gamma + ch * 4);
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
+template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     if (row >= rows) return;
     const int nch = D >> 2;
     const float mu = mean[row], rs = rstd[row];
-    f32x4 g[MAXC], xh[MAXC];
+    f32x4 g[NC], xh[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             const f32x4 d = *(const f32x4*)(dy + (long long)row * lddy + ch * 4);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
             f32x4 o;
@@ -129,8 +131,13 @@ extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_fwd: bad shape rows=%d D=%d", rows, D);
     AIM_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
     AIM_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "layernorm_fwd: strides must be multiples of 4");
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma,
-                       beta, (bf16_t*)y_bf16, y_f32, (long long)ldy, mean, rstd, rows, D, eps);
+#define AIM_LN_FWD(NC)                                                                                            \
+    hipLaunchKernelGGL(ln_fwd_kernel<NC>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, \
+                       gamma, beta, (bf16_t*)y_bf16, y_f32, (long long)ldy, mean, rstd, rows, D, eps)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_LN_FWD(1); else if (nc == 2) AIM_LN_FWD(2); else if (nc == 3) AIM_LN_FWD(3);
+    else if (nc == 4) AIM_LN_FWD(4); else AIM_LN_FWD(8);
+#undef AIM_LN_FWD
     AIM_CHECK_LAUNCH("aim_layernorm_fwd");
     return 0;
 }
@@ -143,9 +150,14 @@ extern "C" int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     AIM_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "layernorm_bwd: null pointer");
     AIM_CHECK_ARG((!dgamma) == (!dbeta), "layernorm_bwd: dgamma and dbeta go together");
     AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (long long)lddy, x,
-                       (long long)ldx, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta,
-                       rows, D);
+#define AIM_LN_BWD(NC)                                                                                             \
+    hipLaunchKernelGGL(ln_bwd_kernel<NC>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (long long)lddy, \
+                       x, (long long)ldx, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, (long long)lddx, dgamma,      \
+                       dbeta, rows, D)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_LN_BWD(1); else if (nc == 2) AIM_LN_BWD(2); else if (nc == 3) AIM_LN_BWD(3);
+    else if (nc == 4) AIM_LN_BWD(4); else AIM_LN_BWD(8);
+#undef AIM_LN_BWD
     AIM_CHECK_LAUNCH("aim_layernorm_bwd");
     return 0;
 }

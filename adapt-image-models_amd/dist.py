@@ -30,6 +30,13 @@ def init_distributed(backend: str = None) -> tuple:
     return rank, local, world
 
 
+def broadcast_module(module: torch.nn.Module, src: int = 0):
+    """Initial parameter/buffer broadcast from rank 0 (what the DDP constructor does, apis/train.py:106)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
 class FlatGradReducer:
     """Owns one flat gradient buffer for ``params`` and mean-all-reduces it in a single collective."""
 
@@ -71,6 +78,85 @@ class FlatGradReducer:
                 dist.broadcast(t.data, src)
 
 
+class FlatAdamW:
+    """AdamW over flat buffers: parameters, gradients and both moments of all trainable tensors live in
+    four contiguous fp32 buffers (``param.data`` / ``param.grad`` are views), grouped by (lr, weight_decay)
+    so that a step is one ``aim_adamw_flat`` launch per group and one all-reduce for the whole model.
+
+    ``groups`` is a list of dicts like torch's param groups: ``{"params": [...], "lr":, "weight_decay":}``.
+    """
+
+    def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        from . import ops
+        self._ops = ops
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        merged = {}
+        for g in groups:
+            key = (float(g.get("lr", lr)), float(g.get("weight_decay", weight_decay)))
+            merged.setdefault(key, []).extend(p for p in g["params"] if p.requires_grad)
+        self.param_groups = []
+        params = []
+        for (glr, gwd), ps in merged.items():
+            self.param_groups.append(dict(params=ps, lr=glr, weight_decay=gwd, betas=betas, eps=eps))
+            params += ps
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev = params[0].device
+        pad = lambda n: (n + 3) // 4 * 4        # keep every tensor 16-byte aligned inside the flat buffers
+        total = sum(pad(p.numel()) for p in params)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        off = 0
+        self._views = []
+        for grp in self.param_groups:
+            grp["range"] = [off, off]
+            for p in grp["params"]:
+                if p.dtype != torch.float32:
+                    raise TypeError("trainable parameters are kept in fp32")
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + n].view_as(p)
+                p.grad = self.flat_g[off:off + n].view_as(p)
+                self._views.append((p, off, n))
+                off += pad(n)
+            grp["range"][1] = off
+        self.step_count = 0
+        self.numel = total
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+        for p, off, n in self._views:
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
+                p.grad = self.flat_g[off:off + n].view_as(p)
+
+    def all_reduce_grads(self):
+        """Mean of the flat gradient over ranks: ONE RCCL all-reduce per step."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.flat_g)
+                self.flat_g.div_(dist.get_world_size())
+
+    def step(self):
+        self.step_count += 1
+        for grp in self.param_groups:
+            a, b = grp["range"]
+            if b > a:
+                self._ops.adamw_flat(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], grp["lr"],
+                                     grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self.step_count)
+
+    def state_dict(self):
+        return dict(step=self.step_count, m=self.flat_m.clone(), v=self.flat_v.clone(),
+                    groups=[dict(lr=g["lr"], weight_decay=g["weight_decay"], range=list(g["range"])) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.flat_m.copy_(sd["m"]); self.flat_v.copy_(sd["v"])
+
+
 def shard_indices(n: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True):
     """DistributedSampler partition (mmaction/datasets/samplers/distributed_sampler.py:36-43): pad to a
     multiple of world, take indices[rank::world]; seed = epoch + seed."""
@@ -107,5 +193,8 @@ def build_optimizer(model: torch.nn.Module, cfg: dict):
                     g["lr"] = base_lr * custom[key]["lr_mult"]
                 break
         groups.append(g)
+    if typ == "AdamW" and all(p.is_cuda for g in groups for p in g["params"]):
+        return FlatAdamW(groups, lr=cfg["lr"], betas=tuple(cfg.get("betas", (0.9, 0.999))), eps=cfg.get("eps", 1e-8),
+                         weight_decay=base_wd)
     opt_cls = getattr(torch.optim, typ)
     return opt_cls(groups, **cfg)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P],
     "aim_cast_bf16": [P, P, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
+    "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],
 }
 
 ABI_VERSION = 1

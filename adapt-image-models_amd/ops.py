@@ -233,3 +233,10 @@ def scale_rows(x, s, y=None, y_f32=None):
     R, C = x.shape
     check(load_library().aim_scale_rows(x.data_ptr(), s.data_ptr(), _p(y), _p(y_f32), R, C, _stream()),
           "aim_scale_rows")
+
+
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    for n_, t_ in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_adamw_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
+                                        beta2, eps, weight_decay, step, _stream()), "aim_adamw_flat")

@@ -94,7 +94,7 @@ def cpu_baseline(frames):
 
 def main():
     args = parse()
-    from aim_amd.dist import FlatGradReducer, build_optimizer, init_distributed
+    from aim_amd.dist import broadcast_module, build_optimizer, init_distributed
     from aim_amd import ops
     rank, local, world = init_distributed()
     if world != args.gpus:
@@ -103,8 +103,7 @@ def main():
     dev = torch.device("cuda", local)
 
     model = build_model(args.frames, dev)
-    reducer = FlatGradReducer(model.parameters())
-    reducer.broadcast_params(model)
+    broadcast_module(model)
     opt = build_optimizer(model, dict(
         type='AdamW', lr=3e-4, betas=(0.9, 0.999), weight_decay=0.05,
         paramwise_cfg=dict(custom_keys={k: dict(decay_mult=0.) for k in
@@ -116,11 +115,11 @@ def main():
     label = torch.randint(0, 400, (B, 1), generator=g).to(dev)
 
     def step():
-        reducer.zero_grad()
+        opt.zero_grad()
         losses = model(imgs, label, return_loss=True)
         loss = losses["loss_cls"]
         loss.backward()
-        reducer.all_reduce()
+        opt.all_reduce_grads()
         opt.step()
         return losses
 
@@ -145,7 +144,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss_val = float(losses["loss_cls"])
+    loss_val = float(losses["loss_cls"].detach())
 
     if rank == 0:
         clips = B * world * args.steps

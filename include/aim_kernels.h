@@ -166,6 +166,15 @@ int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at
 int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, void* stream);
 int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer boundary: AdamW (torch.optim.AdamW semantics, decoupled decay) on ONE flat fp32 buffer
+ * per parameter group -- the reference steps 149 small tensors through mmcv's optimizer hook
+ * (mmaction/utils/optimizer.py:22-33, configs/recognition/vit/vitclip_base_k400.py:96-102).
+ * `step` is the 1-based update count (bias correction).  Pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int aim_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

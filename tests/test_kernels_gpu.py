@@ -37,7 +37,10 @@ def quick_gelu(x):
 
 # ------------------------------------------------------------------ GEMM -----------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (20, 32, 128), (100, 192, 136),
-                                   (394, 2304, 768), (130, 132, 72), (1, 4, 8)])
+                                   (394, 2304, 768), (130, 132, 72), (1, 4, 8),
+                                   # M >= 1024 runs the 256x256 pipelined kernel (gemm256.hip)
+                                   (1024, 256, 64), (2048, 768, 768), (1300, 200, 136), (1576, 3072, 192),
+                                   (1100, 128, 8), (3940, 192, 768), (1182, 768, 3072)])
 def test_gemm_bf16_plain(M, N, K):
     ops = _ops()
     a, w = rnd((M, K), 1, dtype=torch.bfloat16), rnd((N, K), 2, K ** -0.5, torch.bfloat16)
@@ -48,9 +51,10 @@ def test_gemm_bf16_plain(M, N, K):
     close(out, ref, 2e-3, 1e-2, f"gemm {M}x{N}x{K}")
 
 
-def test_gemm_strided_and_rowscale():
+@pytest.mark.parametrize("frames", [6, 260])
+def test_gemm_strided_and_rowscale(frames):
     ops = _ops()
-    ntok, frames, N, K = 5, 6, 64, 128
+    ntok, N, K = 5, 192, 128
     M = ntok * frames
     big = rnd((M, 3 * K), 4, dtype=torch.bfloat16)
     a = big[:, K:2 * K]                      # row stride 3K, column offset K
@@ -62,10 +66,11 @@ def test_gemm_strided_and_rowscale():
     close(out, rs * (a.float() @ w.float().T), 2e-3, 1e-2, "gemm strided+rowscale")
 
 
+@pytest.mark.parametrize("M", [200, 1500])
 @pytest.mark.parametrize("act", [0, 1])
-def test_gemm_act_and_dact(act):
+def test_gemm_act_and_dact(act, M):
     ops = _ops()
-    M, N, K = 200, 192, 128
+    N, K = 192, 128
     a, w = rnd((M, K), 8, dtype=torch.bfloat16), rnd((N, K), 9, K ** -0.5, torch.bfloat16)
     bias = rnd((N,), 10, 0.1)
     post = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
@@ -84,9 +89,10 @@ def test_gemm_act_and_dact(act):
     close(out, (g.float() @ w2.float().T) * x.grad, 3e-3, 1.5e-2, "dact")
 
 
-def test_gemm_f32_residual_forms():
+@pytest.mark.parametrize("frames", [4, 200])
+def test_gemm_f32_residual_forms(frames):
     ops = _ops()
-    ntok, frames, N, K = 7, 4, 128, 192
+    ntok, N, K = 7, 128, 192
     M = ntok * frames
     a, w = rnd((M, K), 13, dtype=torch.bfloat16), rnd((N, K), 14, K ** -0.5, torch.bfloat16)
     bias, resid = rnd((N,), 15), rnd((M, N), 16)
@@ -330,6 +336,38 @@ def test_misc_reductions_and_casts():
     y = torch.zeros((50, 72), dtype=torch.bfloat16, device=DEV)
     ops.scale_rows(src, s, y=y)
     close(y, src * s[:, None], 1e-6, 2 ** -8, "scale_rows")
+
+
+@pytest.mark.parametrize("M,C", [(5000, 768), (300, 192), (64, 32), (100, 20)])
+def test_colsum_shapes(M, C):
+    ops = _ops()
+    X = rnd((M, C), 77, 1.0, torch.bfloat16)
+    out = rnd((C,), 78)
+    ref = out + X.float().sum(0)
+    ops.colsum(X, out)
+    close(out, ref, 2e-3, 1e-4, "colsum")
+
+
+def test_flat_adamw_matches_torch():
+    from aim_amd.dist import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(192, 768), (192,), (768, 192), (768,), (1, 8, 768), (7,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.AdamW([dict(params=qs[:4], weight_decay=0.05), dict(params=qs[4:], weight_decay=0.0)],
+                            lr=3e-4, betas=(0.9, 0.999))
+    opt = FlatAdamW([dict(params=ps[:4], weight_decay=0.05), dict(params=ps[4:], weight_decay=0.0)], lr=3e-4,
+                    betas=(0.9, 0.999), eps=1e-8)
+    for it in range(3):
+        opt.zero_grad(); ref.zero_grad()
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad.add_(g)                    # autograd accumulates into the flat view the same way
+            q.grad = g.clone()
+        opt.step(); ref.step()
+        for p, q in zip(ps, qs):
+            close(p.detach(), q.detach(), 1e-6, 1e-5, f"adamw step {it}")
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in ps)
 
 
 def test_errors_are_loud():
