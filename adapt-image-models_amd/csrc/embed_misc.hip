@@ -208,11 +208,11 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
     const int t = threadIdx.x;
     const int col = t % cg;   // column group
     const int rslot = t / cg;
-    if (rslot >= nrs) return;
+    const bool live = rslot < nrs;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rslot; r < r1; r += nrs) {
+    for (int r = r0 + rslot; live && r < r1; r += nrs) {
         float rs = 1.f;
         if (af || at) {
             const int f = r / ntok, tk = r - f * ntok;
@@ -223,8 +223,20 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += rs * (float)v[e];
     }
+    // reduce the row slots of this block through LDS, then ONE atomic per column per block
+    __shared__ float red[256 * 8];
+    if (live) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + col * 8 + e, acc[e]);
+        for (int e = 0; e < 8; ++e) red[(rslot * cg + col) * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (rslot == 0) {
+        for (int s2 = 1; s2 < nrs; ++s2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += red[(s2 * cg + col) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(out + col * 8 + e, acc[e]);
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
@@ -372,8 +384,8 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
     AIM_CHECK_ARG(M > 0 && C > 0 && X && out, "colsum: bad arguments");
     if (af || at) AIM_CHECK_ARG(ntok > 0, "colsum: ntok required with row factors");
     if ((C % 8) == 0 && C <= 2048 && (ldx % 8) == 0) {
-        int rpb8 = (M + 1023) / 1024;
-        if (rpb8 < 32) rpb8 = 32;
+        int rpb8 = (M + 255) / 256;          // <= 256 blocks: one atomic per column per block
+        if (rpb8 < 64) rpb8 = 64;
         hipLaunchKernelGGL(colsum8_kernel, dim3(1, (M + rpb8 - 1) / rpb8), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)X, ldx, af, at, ntok, out, M, C, rpb8);
         AIM_CHECK_LAUNCH("aim_colsum_bf16");
