@@ -178,9 +178,9 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     AIM_CHECK_ARG((long long)128 * g.lda * 2 < 0x7fffffffLL && (long long)128 * g.ldw * 2 < 0x7fffffffLL, "gemm: leading dimension too large");
     if (g.af || g.at || g.vec) AIM_CHECK_ARG(g.ntok > 0, "gemm: ntok required with row factors");
     // large-M problems run on the 256x256 pipelined kernel (gemm256.hip); AIM_GEMM_TILE=128 forces v1
-    static const int force128 = [] { const char* e = getenv("AIM_GEMM_TILE"); return e && atoi(e) == 128; }();
-    if (!force128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 128)
-        return aim_gemm256_launch(g, epi, st);
+    // large-M problems run on the 256x256 pipelined kernel (gemm256.hip); AIM_GEMM_TILE=128 forces this file's
+    static const int pick = [] { const char* e = getenv("AIM_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64) return aim_gemm256_launch(g, epi, st);
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(g, batch, st);
         case EPI_ACT:

@@ -22,6 +22,7 @@
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -181,64 +182,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     // 4 rows x 64 consecutive columns (16 lanes x 4 columns per row): residual / aux loads and the
     // output stores are then whole 128-256 B lines instead of 8-16 B fragments per lane.
     AIM_BAR();                                    // every wave is done reading the K-loop images
-    {
-        constexpr int RS = 272;                   // padded row stride (64 f32 + 16 B)
-        AIM_LDS char* scr = smem + wave * (32 * RS);
-        const int rr = lane >> 4, cc = (lane & 15) * 4;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *(AIM_LDS f32x4*)(scr + (ii * 16 + frow) * RS + (j * 16 + fq * 4) * 4) = acc[pass * 2 + ii][j];
-            if constexpr (EPI != EPI_BF16) {
-                FragIn fin[8];
-                const int n = n0 + wn * 64 + cc;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int m = m0 + wm * 128 + pass * 32 + t * 4 + rr;
-                    if (m < g.M && n < g.N) fin[t] = load_frag_in<EPI>(g, m, n);
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int r = t * 4 + rr;
-                    const f32x4 v = *(const AIM_LDS f32x4*)(scr + r * RS + cc * 4);
-                    const int m = m0 + wm * 128 + pass * 32 + r;
-                    if (m < g.M && n < g.N) store_frag<EPI>(g, v, m, n, row_factors(g, m), fin[t]);
-                }
-            } else {
-                // bf16 outputs: 8 lanes x 8 columns per row, 8 rows per wave-instruction, 16-byte stores
-                const int r8 = lane >> 3, c8 = (lane & 7) * 8;
-                const int n = n0 + wn * 64 + c8;
-                const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N &&
-                                  (EPI != EPI_ACT || (g.ldo2 % 8) == 0) && (EPI != EPI_DACT || (g.ldaux % 8) == 0);
-                bf16x8 aux8[4];
-                if constexpr (EPI == EPI_DACT) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int m = m0 + wm * 128 + pass * 32 + t * 8 + r8;
-                        if (m < g.M && wide) aux8[t] = *(const bf16x8*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int r = t * 8 + r8;
-                    const f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r * RS + c8 * 4);
-                    const f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r * RS + c8 * 4 + 16);
-                    const int m = m0 + wm * 128 + pass * 32 + r;
-                    if (m >= g.M || n >= g.N) continue;
-                    const RowFactors rf = row_factors(g, m);
-                    if (wide) {
-                        store_frag8<EPI>(g, v0, v1, m, n, rf, aux8[t]);
-                    } else {   // ragged N / odd strides: 4-column form
-                        store_frag<EPI>(g, v0, m, n, rf);
-                        if (n + 4 < g.N) store_frag<EPI>(g, v1, m, n + 4, rf);
-                    }
-                }
-            }
-        }
-    }
+    wave_epilogue<EPI>(g, acc, smem + wave * EPI_SCRATCH, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 template <int EPI>

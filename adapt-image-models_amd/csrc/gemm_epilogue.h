@@ -121,3 +121,141 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
     }
     *(bf16x8*)((bf16_t*)g.out + (long long)m * g.ldo + n) = o;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue of one wave's 128x64 accumulator tile (acc[8][4], 16x16 MFMA fragments), re-tiled through a
+// private LDS scratch (16 rows x 272 B) so global accesses are whole 128-256 B row segments.
+// Memory-side inputs are software-pipelined: the loads of row-block p+1 are issued BEFORE the stores
+// of row-block p, so a wave never waits on a store acknowledgement (vmcnt is in-order and counts
+// stores) and keeps two row-blocks of loads in flight.  Column-only inputs (bias) are loaded once.
+// ------------------------------------------------------------------------------------------------
+constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad
+constexpr int EPI_ROWS = 32;                     // rows per pass (two 16-row MFMA tiles)
+constexpr int EPI_SCRATCH = EPI_ROWS * EPI_RS;   // bytes per wave
+
+template <int EPI>
+struct RowIn {       // memory-side inputs of one (row, lane) 4-column fragment
+    f32x4 resid;
+    bf16x4 aux;
+};
+
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base,
+                                              int n_base, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    auto dump = [&](int p) {       // two MFMA row-tiles -> scratch rows 0..31
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(AIM_LDS f32x4*)(scr + (ii * 16 + frow) * EPI_RS + (j * 16 + fq * 4) * 4) = acc[p * 2 + ii][j];
+    };
+    const bool rowf = g.af || g.at || g.vec;
+    if constexpr (EPI == EPI_BF16) {
+        // 8 lanes x 8 columns per row, 8 rows per wave-instruction, 16-byte stores, no memory inputs but bias
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int n = n_base + c8;
+        const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N;
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (g.bias && n < g.N) {
+            b0 = *(const f32x4*)(g.bias + n);
+            if (n + 4 < g.N) b1 = *(const f32x4*)(g.bias + n + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            dump(p);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = t * 8 + r8;
+                f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + c8 * 4);
+                f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + c8 * 4 + 16);
+                const int m = m_base + p * 32 + r;
+                if (m >= g.M || n >= g.N) continue;
+                float rs = 1.0f;
+                if (rowf) rs = row_factors(g, m).rs;
+                v0 = (v0 + b0) * rs;
+                v1 = (v1 + b1) * rs;
+                bf16_t* o = (bf16_t*)g.out + (long long)m * g.ldo + n;
+                if (wide) {
+                    bf16x8 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w[e] = (bf16_t)v0[e];
+                        w[4 + e] = (bf16_t)v1[e];
+                    }
+                    *(bf16x8*)o = w;
+                } else {
+                    *(bf16x4*)o = pack4(v0[0], v0[1], v0[2], v0[3]);
+                    if (n + 4 < g.N) *(bf16x4*)(o + 4) = pack4(v1[0], v1[1], v1[2], v1[3]);
+                }
+            }
+        }
+    } else {
+        const int rr = lane >> 4, cc = (lane & 15) * 4;
+        const int n = n_base + cc;
+        const bool ncol = n < g.N;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.bias && ncol) bias4 = *(const f32x4*)(g.bias + n);
+        constexpr bool HAS_IN = (EPI == EPI_F32 || EPI == EPI_DACT);
+        auto load_rows = [&](int p, RowIn<EPI> (&ri)[8]) {
+            if constexpr (HAS_IN) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int m = m_base + p * 32 + t * 4 + rr;
+                    ri[t].resid = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m < g.M && ncol) {
+                        if constexpr (EPI == EPI_F32) {
+                            if (g.resid) ri[t].resid = *(const f32x4*)(g.resid + (long long)m * g.ldr + n);
+                        }
+                        if constexpr (EPI == EPI_DACT)
+                            ri[t].aux = *(const bf16x4*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
+                    }
+                }
+            }
+        };
+        auto finish = [&](int p, const RowIn<EPI> (&ri)[8]) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = t * 4 + rr;
+                f32x4 v = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + cc * 4);
+                const int m = m_base + p * 32 + r;
+                if (m >= g.M || !ncol) continue;
+                RowFactors rf{1.0f, 0.0f, 0};
+                if (rowf) rf = row_factors(g, m);
+                const float rs = rf.rs;
+                if (EPI == EPI_F32 && g.rs_bias_only) v += rs * bias4; else v += bias4;
+                if constexpr (EPI == EPI_ACT) {
+                    const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
+                    *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = (float)pre[e];
+                        a[e] = rs * (g.act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
+                    }
+                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
+                } else if constexpr (EPI == EPI_DACT) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = (float)ri[t].aux[e];
+                        a[e] = rs * v[e] * (g.act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
+                    }
+                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
+                } else {   // EPI_F32
+                    if (!g.rs_bias_only) v *= rs;
+                    if (g.vec) v += rf.vs * *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
+                    v += ri[t].resid;
+                    *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
+                }
+            }
+        };
+        // loads of pass p+1 are issued before the stores of pass p: a wave never waits on a store ack
+        RowIn<EPI> ra[8], rb[8];
+        load_rows(0, ra);
+        dump(0); load_rows(1, rb); finish(0, ra);
+        dump(1); load_rows(2, ra); finish(1, rb);
+        dump(2); load_rows(3, rb); finish(2, ra);
+        dump(3); finish(3, rb);
+    }
+}
