@@ -104,13 +104,41 @@ class _Frozen:
         a = blk.attn
         self.Wqkv, self.WqkvT = _cast(a.in_proj_weight), _cast(a.in_proj_weight, True)
         self.Wo, self.WoT = _cast(a.out_proj.weight), _cast(a.out_proj.weight, True)
-        self.Wfc, self.WfcT = _cast(blk.mlp.c_fc.weight), _cast(blk.mlp.c_fc.weight, True)
-        self.Wpr, self.WprT = _cast(blk.mlp.c_proj.weight), _cast(blk.mlp.c_proj.weight, True)
+        # Frozen MLP and the trainable MLP_Adapter share their GEMMs (same input xn, outputs summed): the
+        # operands are concatenated once -- [W_fc ; D_fc1] along N, [W_proj | D_fc2] along K -- and only the
+        # adapter slices are re-cast each step (stage_mlp_adapter).  Both orientations for fwd and dgrad.
+        D = blk.d_model
+        r = blk.MLP_Adapter.D_fc1.weight.shape[0]
+        dev = a.in_proj_weight.device
+        self.D, self.r, self.H4 = D, r, 4 * D
+        self.Wcat1 = torch.empty((4 * D + r, D), dtype=BF16, device=dev)      # [W_fc ; W1]      fwd  (N-concat)
+        self.Wcat2 = torch.empty((D, 4 * D + r), dtype=BF16, device=dev)      # [W_proj | W2]    fwd  (K-concat)
+        self.WcatT2 = torch.empty((4 * D + r, D), dtype=BF16, device=dev)     # [W_proj^T ; W2^T] dgrad (N-concat)
+        self.WcatT1 = torch.empty((D, 4 * D + r), dtype=BF16, device=dev)     # [W_fc^T | W1^T]   dgrad (K-concat)
+        wfc, wpr = blk.mlp.c_fc.weight.detach().float().contiguous(), blk.mlp.c_proj.weight.detach().float().contiguous()
+        ops.cast_bf16(wfc, self.Wcat1[:4 * D])
+        ops.cast_bf16(wpr, self.Wcat2[:, :4 * D])
+        ops.cast_bf16(wpr, self.WcatT2[:4 * D], transpose=True)
+        ops.cast_bf16(wfc, self.WcatT1[:, :4 * D], transpose=True)
+        self.bcat1 = torch.zeros(4 * D + r, dtype=F32, device=dev)
+        self.bcat1[:4 * D] = blk.mlp.c_fc.bias.detach().float()
         f = lambda p: p.detach().float().contiguous()
         self.bqkv, self.bo = f(a.in_proj_bias), f(a.out_proj.bias)
-        self.bfc, self.bpr = f(blk.mlp.c_fc.bias), f(blk.mlp.c_proj.bias)
+        self.bpr = f(blk.mlp.c_proj.bias)
         self.g1, self.b1 = f(blk.ln_1.weight), f(blk.ln_1.bias)
         self.g2, self.b2 = f(blk.ln_2.weight), f(blk.ln_2.bias)
+
+
+    def stage_mlp_adapter(self, w1, b1, w2, b2):
+        """Write this step's MLP_Adapter weights into the adapter slices of the concatenated operands."""
+        H4 = self.H4
+        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        ops.cast_bf16(w1f, self.Wcat1[H4:])                       # [r, D]
+        ops.cast_bf16(w2f, self.Wcat2[:, H4:])                    # [D, r]
+        ops.cast_bf16(w2f, self.WcatT2[H4:], transpose=True)      # [r, D]
+        ops.cast_bf16(w1f, self.WcatT1[:, H4:], transpose=True)   # [D, r]
+        self.bcat1[H4:] = b1.detach().float()
+        self.b2row = b2.detach().float().reshape(1, -1).contiguous()
 
 
 class _AdapterW:
@@ -143,7 +171,7 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     dev = x.device
     M, D = x.shape
     BT = B * T
-    r = adp["MLP_Adapter"].W1.shape[0]
+    r = fz.r
     # ln_1 (once) + fused QKV projection
     xl = _empty((M, D), BF16, dev)
     mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
@@ -185,20 +213,21 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     xn = _empty((M, D), BF16, dev)
     mean2, rstd2 = _empty((M,), F32, dev), _empty((M,), F32, dev)
     ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
-    h_pre, h = _empty((M, 4 * D), BF16, dev), _empty((M, 4 * D), BF16, dev)
-    ops.gemm(xn, fz.Wfc, ops.EPI_ACT, h, bias=fz.bfc, out2=h_pre, act=ops.ACT_QGELU)
-    ma = adp["MLP_Adapter"]
-    a_pre, a_s = _empty((M, r), BF16, dev), _empty((M, r), BF16, dev)
-    ops.gemm(xn, ma.W1, ops.EPI_ACT, a_s, bias=ma.b1, out2=a_pre, act=ops.ACT_GELU, at=dms2, ntok=N)
+    # one GEMM for [c_fc | D_fc1] (N = 4D + r; QuickGELU on the MLP columns, dms2 * GELU on the adapter's)
+    # and one for [c_proj | D_fc2] (K = 4D + r); the adapter's token-scaled bias rides along as `vec`.
+    H4 = 4 * D
+    hcat_pre, hcat = _empty((M, H4 + r), BF16, dev), _empty((M, H4 + r), BF16, dev)
+    ops.gemm(xn, fz.Wcat1, ops.EPI_ACT, hcat, bias=fz.bcat1, out2=hcat_pre, act=ops.ACT_QGELU, n_split=H4,
+             act2=ops.ACT_GELU, at=dms2, ntok=N)
     x2 = _empty((M, D), F32, dev)
-    ops.gemm(h, fz.Wpr, ops.EPI_F32, x2, bias=fz.bpr, resid=x1)
-    del h
-    ops.gemm(a_s, ma.W2, ops.EPI_F32, x2, bias=ma.b2, resid=x2, at=dms2, ntok=N, rs_bias_only=True)
+    ops.gemm(hcat, fz.Wcat2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
+    a_s = hcat[:, H4:].contiguous() if save else None
+    del hcat
     ctx = None
     if save:
         ctx = dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, probs=probs, ta=ta, t_pre=t_pre, t_h=t_h, lam=lam,
                    oml=oml, ao=ao, lse=lse, sin=sin, s_pre=s_pre, s_h=s_h, x1=x1, mean2=mean2, rstd2=rstd2, xn=xn,
-                   h_pre=h_pre, a_pre=a_pre, a_s=a_s, dms1=dms1, dms2=dms2)
+                   hcat_pre=hcat_pre, a_s=a_s, dms1=dms1, dms2=dms2)
     return x2, ctx
 
 
@@ -218,22 +247,18 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     dev = dx2.device
     M, D = dx2.shape
     BT = B * T
-    r = adp["MLP_Adapter"].W1.shape[0]
-    ma, gm = adp["MLP_Adapter"], grads["MLP_Adapter"]
-    # ---- MLP_Adapter: x2 += dms2[tok] * (gelu(xn W1^T + b1) W2^T + b2); a_s = dms2 * gelu(.)
+    r, H4 = fz.r, 4 * D
+    gm = grads["MLP_Adapter"]
+    # ---- MLP + MLP_Adapter: x2 = x1 + [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2
     ops.colsum(dyb, gm["D_fc2.bias"], at=c["dms2"], ntok=N)
     ops.wgrad(dyb, c["a_s"], gm["D_fc2.weight"])
-    da_pre = _empty((M, r), BF16, dev)
-    ops.gemm(dyb, ma.W2T, ops.EPI_DACT, da_pre, aux=c["a_pre"], act=ops.ACT_GELU, at=c["dms2"], ntok=N)
-    ops.wgrad(da_pre, c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
-    # ---- frozen MLP (dgrad only)
-    dh_pre = _empty((M, 4 * D), BF16, dev)
-    ops.gemm(dyb, fz.WprT, ops.EPI_DACT, dh_pre, aux=c["h_pre"], act=ops.ACT_QGELU)
+    dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
+    ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=c["hcat_pre"], act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
+             at=c["dms2"], ntok=N)
+    ops.wgrad(dcat[:, H4:], c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
     dxn = _empty((M, D), F32, dev)
-    ops.gemm(dh_pre, fz.WfcT, ops.EPI_F32, dxn)
-    del dh_pre
-    ops.gemm(da_pre, ma.W1T, ops.EPI_F32, dxn, resid=dxn)
-    del da_pre
+    ops.gemm(dcat, fz.WcatT1, ops.EPI_F32, dxn)      # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
+    del dcat
     # ---- ln_2
     dx1, dx1b = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
     ops.layernorm_bwd(dxn, c["x1"], fz.g2, c["mean2"], c["rstd2"], M, D, lddy=D, ldx=D, lddx=D, dres=dx2, dx=dx1,
@@ -300,7 +325,10 @@ class _BackboneFn(torch.autograd.Function):
             d = {}
             for j, a in enumerate(_ADAPTERS):
                 k = 3 + (i * 3 + j) * 4
-                d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3])
+                if a == "MLP_Adapter":      # shares the frozen MLP's GEMMs: staged into the concatenated operands
+                    frozen["blocks"][i].stage_mlp_adapter(params[k], params[k + 1], params[k + 2], params[k + 3])
+                else:
+                    d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3])
             adp.append(d)
         # patch embedding as a GEMM (conv1: kernel = stride = patch, no bias; vit_clip.py:436)
         Kp = frozen["conv"].shape[1]

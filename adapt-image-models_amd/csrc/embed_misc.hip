@@ -249,9 +249,18 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     }
 }
 
+// row-strided destination: dst[r * ldd + c] = src[r * C + c]
+__global__ __launch_bounds__(256) void cast_strided_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R,
+                                                           int C, int ldd) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R * C) return;
+    const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+    dst[(long long)r * ldd + c] = (bf16_t)src[i];
+}
+
 // dst[c][r] = src[r][c]
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
-                                                             int R, int C) {
+                                                             int R, int C, int ldd) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
-        if (c < C && r < R) dst[(long long)c * R + r] = (bf16_t)tile[tx][j];
+        if (c < C && r < R) dst[(long long)c * ldd + r] = (bf16_t)tile[tx][j];
     }
 }
 
@@ -399,11 +408,16 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
     return 0;
 }
 
-extern "C" int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, void* stream) {
+extern "C" int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, int ldd, void* stream) {
     AIM_CHECK_ARG(R > 0 && C > 0 && src && dst, "cast: bad arguments");
+    AIM_CHECK_ARG(ldd == 0 || ldd >= (transpose ? R : C), "cast: ldd=%d smaller than the destination row", ldd);
     hipStream_t st = (hipStream_t)stream;
     if (transpose) {
-        hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, (bf16_t*)dst, R, C);
+        hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, (bf16_t*)dst, R, C,
+                           ldd ? ldd : R);
+    } else if (ldd && ldd != C) {
+        const long long n = (long long)R * C;
+        hipLaunchKernelGGL(cast_strided_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (bf16_t*)dst, R, C, ldd);
     } else {
         const long long n = (long long)R * C;
         hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, (bf16_t*)dst, n);

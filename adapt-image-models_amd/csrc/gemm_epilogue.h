@@ -9,6 +9,12 @@ struct RowFactors {
     int frame;
 };
 
+// column-split epilogues (fused [frozen MLP | adapter] GEMMs): activation kind and row factor for column n
+__device__ __forceinline__ int col_act(const GemmArgs& g, int n) { return (g.n_split > 0 && n >= g.n_split) ? g.act2 : g.act; }
+__device__ __forceinline__ float col_rs(const GemmArgs& g, int n, float rs) {
+    return (g.n_split > 0 && n < g.n_split) ? 1.0f : rs;
+}
+
 __device__ __forceinline__ RowFactors row_factors(const GemmArgs& g, int m) {
     RowFactors r{1.0f, 0.0f, 0};
     if (g.af || g.at || g.vec) {
@@ -42,7 +48,8 @@ __device__ __forceinline__ FragIn load_frag_in(const GemmArgs& g, int m, int n) 
 template <int EPI>
 __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, int n, const RowFactors& rf,
                                            const FragIn& fin) {
-    const float rs = rf.rs;
+    const float rs = (EPI == EPI_ACT || EPI == EPI_DACT) ? col_rs(g, n, rf.rs) : rf.rs;
+    const int act = col_act(g, n);
     if (g.bias) {
         const f32x4 b = *(const f32x4*)(g.bias + n);
         if (EPI == EPI_F32 && g.rs_bias_only) v += rs * b; else v += b;
@@ -54,7 +61,7 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, in
         const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
         *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
         const float p0 = (float)pre[0], p1 = (float)pre[1], p2 = (float)pre[2], p3 = (float)pre[3];
-        const bf16x4 post = (g.act == ACT_QGELU)
+        const bf16x4 post = (act == ACT_QGELU)
                                 ? pack4(rs * quick_gelu(p0), rs * quick_gelu(p1), rs * quick_gelu(p2), rs * quick_gelu(p3))
                                 : pack4(rs * gelu_erf(p0), rs * gelu_erf(p1), rs * gelu_erf(p2), rs * gelu_erf(p3));
         *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = post;
@@ -63,7 +70,7 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, in
         float d[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            d[e] = (g.act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
+            d[e] = (act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
         *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) =
             pack4(rs * v[0] * d[0], rs * v[1] * d[1], rs * v[2] * d[2], rs * v[3] * d[3]);
     } else if constexpr (EPI == EPI_F32) {
@@ -88,7 +95,8 @@ template <int EPI>
 __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v1, int m, int n, const RowFactors& rf,
                                             const bf16x8& aux8) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_ACT || EPI == EPI_DACT, "bf16-output epilogues only");
-    const float rs = rf.rs;
+    const float rs = (EPI == EPI_BF16) ? rf.rs : col_rs(g, n, rf.rs);
+    const int act = col_act(g, n);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     if (g.bias) {
         const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
@@ -110,13 +118,13 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float p = (float)pre[e];
-            o[e] = (bf16_t)(rs * (g.act == ACT_QGELU ? quick_gelu(p) : gelu_erf(p)));
+            o[e] = (bf16_t)(rs * (act == ACT_QGELU ? quick_gelu(p) : gelu_erf(p)));
         }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float p = (float)aux8[e];
-            o[e] = (bf16_t)(rs * v[e] * (g.act == ACT_QGELU ? quick_gelu_grad(p) : gelu_erf_grad(p)));
+            o[e] = (bf16_t)(rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(p) : gelu_erf_grad(p)));
         }
     }
     *(bf16x8*)((bf16_t*)g.out + (long long)m * g.ldo + n) = o;
@@ -196,6 +204,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         const bool ncol = n < g.N;
         f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (g.bias && ncol) bias4 = *(const f32x4*)(g.bias + n);
+        const int act = col_act(g, n);
+        const bool rs_on = !(EPI == EPI_ACT || EPI == EPI_DACT) || g.n_split == 0 || n >= g.n_split;
         constexpr bool HAS_IN = (EPI == EPI_F32 || EPI == EPI_DACT);
         auto load_rows = [&](int p, RowIn<EPI> (&ri)[8]) {
             if constexpr (HAS_IN) {
@@ -221,7 +231,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 const int m = m_base + p * 32 + r;
                 if (m >= g.M || !ncol) continue;
                 RowFactors rf{1.0f, 0.0f, 0};
-                if (rowf) rf = row_factors(g, m);
+                if (rowf && rs_on) rf = row_factors(g, m);
                 const float rs = rf.rs;
                 if (EPI == EPI_F32 && g.rs_bias_only) v += rs * bias4; else v += bias4;
                 if constexpr (EPI == EPI_ACT) {
@@ -231,7 +241,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = (float)pre[e];
-                        a[e] = rs * (g.act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
+                        a[e] = rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
                     }
                     *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
                 } else if constexpr (EPI == EPI_DACT) {
@@ -239,7 +249,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = (float)ri[t].aux[e];
-                        a[e] = rs * v[e] * (g.act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
+                        a[e] = rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
                     }
                     *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
                 } else {   // EPI_F32

@@ -26,7 +26,7 @@ class GemmArgs(Structure):
         ("ldv", c_int32), ("ntok", c_int32),
         ("aux", c_void_p), ("ldaux", c_int32),
         ("out", c_void_p), ("ldo", c_int32), ("out2", c_void_p), ("ldo2", c_int32),
-        ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32),
+        ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32), ("n_split", c_int32), ("act2", c_int32),
     ]
 
 
@@ -54,7 +54,7 @@ SIGNATURES = {
     "aim_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "aim_frame_sum": [P, P, P, I, I, I, P],
     "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P],
-    "aim_cast_bf16": [P, P, I, I, I, P],
+    "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
     "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],
 }

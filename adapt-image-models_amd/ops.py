@@ -69,7 +69,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
          af=None, at=None, vec=None, bt=None, ntok: int = 0, aux=None, out2=None, act: int = 0,
          scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
          stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
-         lda: Optional[int] = None, ldw: Optional[int] = None):
+         lda: Optional[int] = None, ldw: Optional[int] = None, ldv: Optional[int] = None, n_split: int = 0,
+         act2: int = 0):
     """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
     lib = load_library()
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -87,7 +88,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     g.bias, g.resid = _p(bias), _p(resid)
     g.ldr = resid.stride(0) if resid is not None else 0
     g.af, g.at, g.vec, g.bt = _p(af), _p(at), _p(vec), _p(bt)
-    g.ldv = vec.stride(0) if vec is not None else 0
+    g.ldv = (vec.stride(0) if ldv is None else ldv) if vec is not None else 0
     g.ntok = ntok
     g.aux = _p(aux)
     g.ldaux = aux.stride(0) if aux is not None else 0
@@ -96,6 +97,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     g.out2 = _p(out2)
     g.ldo2 = out2.stride(0) if out2 is not None else 0
     g.scale, g.act, g.rs_bias_only = scale, act, int(rs_bias_only)
+    g.n_split, g.act2 = n_split, act2
     if epi in (EPI_BF16, EPI_ACT, EPI_DACT):
         _chk(out, BF16, "out")
     else:
@@ -222,9 +224,11 @@ def colsum(X, out, *, af=None, at=None, ntok=0):
 
 
 def cast_bf16(src, dst, transpose=False):
+    """``dst = bf16(src)`` or ``bf16(src.T)``; ``dst`` may be a column slice of a wider matrix (row-strided)."""
     _chk(src, F32, "src"); _chk(dst, BF16, "dst")
     R, C = src.shape
-    check(load_library().aim_cast_bf16(src.data_ptr(), dst.data_ptr(), R, C, int(transpose), _stream()),
+    assert tuple(dst.shape) == ((C, R) if transpose else (R, C)) and src.is_contiguous()
+    check(load_library().aim_cast_bf16(src.data_ptr(), dst.data_ptr(), R, C, int(transpose), dst.stride(0), _stream()),
           "aim_cast_bf16")
 
 

@@ -76,6 +76,9 @@ typedef struct aim_gemm_args {
     float scale;            /* logit scale (AIM_EPI_EXPSUM)                                     */
     int32_t act;            /* AIM_ACT_*                                                        */
     int32_t rs_bias_only;   /* AIM_EPI_F32: apply rs to the bias term only                      */
+    /* column split for fused [frozen MLP | adapter] GEMMs (ACT / DACT): when n_split > 0, columns
+       n < n_split use `act` with rs = 1, columns n >= n_split use `act2` with the row factor rs   */
+    int32_t n_split, act2;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
@@ -163,7 +166,8 @@ int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const 
 int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream);
 int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok,
                     float* out, int M, int C, void* stream);
-int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, void* stream);
+int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, int ldd /* dst row stride, 0 = dense */,
+                  void* stream);
 int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
