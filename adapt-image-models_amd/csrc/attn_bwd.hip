@@ -4,7 +4,7 @@
 // Autograd counterpart of reference vit_clip.py:139-156 (the reference relies on torch autograd
 // through bmm/softmax/bmm and keeps the [BT,H,N,N] probabilities alive for it).
 //
-// Two kernels per call, one workgroup (4 waves) per (frame, head) each:
+// Two kernels per call, one workgroup per (frame, head) each (dq: 8 waves; dkv: 4 waves, 120 VGPRs):
 //   dq : query on the MFMA lane (same orientation as the forward).  Per 16-query tile and per pair
 //        of 16-key tiles:  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta) / 8 and
 //        dQ^T += K^T dS^T with the dS^T accumulators used directly as the MFMA's second operand
@@ -20,7 +20,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N,
                                                           int H, int nkt) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         __amdgpu_buffer_rsrc_t rK = make_rsrc(base + D, ((long long)(N - 1) * ld + 64) * 2);
         __amdgpu_buffer_rsrc_t rV = make_rsrc(base + 2 * D, ((long long)(N - 1) * ld + 64) * 2);
         const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-        for (int p = wave; p < nkt * 2; p += 4) {
+        for (int p = wave; p < nkt * 2; p += 8) {
             const int key = p * 8 + srow;
             const unsigned voff = key < N ? (unsigned)((key * ld + schunk * 8) * 2) : AIM_OOB;
             stage_piece(rK, sK + p * 1024, voff);
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     __syncthreads();
 
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += 8) {
+        asm volatile("" ::: "memory");          // keep the (qt-invariant) K/V fragment reads inside the loop
         const int q = qt * 16 + frow;
         const int qc = q < N ? q : N - 1;
         bf16x8 qf[2], dof[2];
@@ -253,7 +254,7 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
     hipStream_t st = (hipStream_t)stream;
     const int nkt = ((N + 31) / 32) * 2;   // 16-key tiles, even
     const int nq32 = ((N + 31) / 32) * 32;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(BT * H), dim3(256), nkt * 16 * 128 * 2, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(BT * H), dim3(512), nkt * 16 * 128 * 2, st, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, nkt);
     AIM_CHECK_LAUNCH("aim_attn_bwd(dq)");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(BT * H), dim3(256), nq32 * 128 * 2 + nq32 * 8, st, (const bf16_t*)qkv,

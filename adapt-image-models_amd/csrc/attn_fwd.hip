@@ -4,7 +4,7 @@
 // @v, merge heads) for the spatial call at :264.  The [BT,H,N,N] score tensor the reference
 // materialises (0.95 GB fp32 per layer at config 2) never leaves the CU.
 //
-// One workgroup (4 waves) per (frame, head).  K and V of that head (N <= 288 keys x 64) are staged
+// One workgroup (8 waves, two workgroups per CU) per (frame, head).  K and V of that head (N <= 288 keys x 64) are staged
 // once into swizzled LDS images by buffer_load...lds (zero-filled past N).  Each wave takes 16-row
 // query tiles round-robin:  S^T = K Q^T with the KEY on the MFMA row and the QUERY on the lane, so a
 // query's whole score row sits in one lane quartet (2 shuffles per reduction) and the normalised
@@ -17,8 +17,8 @@
 namespace {
 
 template <int NKT>  // number of 16-key tiles (even)
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int H) {
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, int N, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
     AIM_LDS char* sV = sK + NKT * 16 * 128;
@@ -28,13 +28,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
+    constexpr int NW = 8;                      // waves per workgroup
+    const float C2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(dh) * log2(e): softmax runs in base 2
 
     const bf16_t* base = qkv + (long long)bt * N * ld + h * 64;
+    const int nqt = (N + 15) >> 4;
+    // first query tile's fragments are requested before the K/V staging so their latency overlaps it
+    bf16x8 qf[2];
+    {
+        const int q0 = wave * 16 + frow;
+        const int qc = q0 < N ? q0 : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qc * ld + (ks * 4 + fq) * 8);
+    }
     {
         __amdgpu_buffer_rsrc_t rK = make_rsrc(base + D, ((long long)(N - 1) * ld + 64) * 2);
         __amdgpu_buffer_rsrc_t rV = make_rsrc(base + 2 * D, ((long long)(N - 1) * ld + 64) * 2);
         const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-        for (int p = wave; p < NKT * 2; p += 4) {
+        for (int p = wave; p < NKT * 2; p += NW) {
             const int key = p * 8 + srow;
             const unsigned voff = key < N ? (unsigned)((key * ld + schunk * 8) * 2) : AIM_OOB;
             stage_piece(rK, sK + p * 1024, voff);
@@ -44,14 +55,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
+        // the K/V fragments do not depend on qt: without this fence LICM hoists all 28 K fragments
+        // (112 VGPRs) out of the loop and the kernel spills
+        asm volatile("" ::: "memory");
         const int q = qt * 16 + frow;
-        const int qc = q < N ? q : N - 1;
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qc * ld + (ks * 4 + fq) * 8);
-
         f32x4 s[NKT];
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -62,32 +70,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
-        // softmax over keys: lane holds keys t*16 + fq*4 + e for query (lane & 15)
+        // prefetch the next query tile of this wave
+        if (qt + NW < nqt) {
+            const int qn = (qt + NW) * 16 + frow;
+            const int qc = qn < N ? qn : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (long long)qc * ld + (ks * 4 + fq) * 8);
+        }
+        // softmax over keys (lane holds keys t*16 + fq*4 + e of query lane&15); only tiles that straddle N mask
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NKT; ++t)
+        for (int t = 0; t < NKT; ++t) {
+            if (t * 16 + 16 > N) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = t * 16 + fq * 4 + e;
-                const float v = key < N ? s[t][e] * 0.125f : -INFINITY;
-                s[t][e] = v;
-                mx = fmaxf(mx, v);
+                for (int e = 0; e < 4; ++e)
+                    if (t * 16 + fq * 4 + e >= N) s[t][e] = -INFINITY;
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][e]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * C2;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = __expf(s[t][e] - mx);
+                const float p = __builtin_amdgcn_exp2f(s[t][e] * C2 - mc);   // unnormalised, max = 1
                 s[t][e] = p;
                 sum += p;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
-        if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx + __logf(sum);
+        if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx * 0.125f + __logf(sum);
 
         f32x4 o[4];
 #pragma unroll
@@ -97,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             bf16x8 pf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pf[e] = (bf16_t)(s[2 * kk][e] * inv);
-                pf[4 + e] = (bf16_t)(s[2 * kk + 1][e] * inv);
+                pf[e] = (bf16_t)s[2 * kk][e];
+                pf[4 + e] = (bf16_t)s[2 * kk + 1][e];
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -120,14 +137,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         if (q < N) {
             bf16_t* op = out + ((long long)bt * N + q) * D + h * 64 + fq * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = pack4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            for (int dt = 0; dt < 4; ++dt)
+                *(bf16x4*)(op + dt * 16) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
         }
     }
 }
 
 template <int NKT>
 int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
-    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(BT * H), dim3(256), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
                        (bf16_t*)out, lse, N, H);
     AIM_CHECK_LAUNCH("aim_attn_fwd");
     return 0;

@@ -363,8 +363,9 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     qh = q.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
     kh = k.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
     vh = v.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
-    p = ((qh @ kh.transpose(-1, -2)) / math.sqrt(dh)).softmax(-1)
-    ao = rnd((rnd(p) @ vh).permute(0, 2, 1, 3).reshape(BT, N, D))
+    sc = (qh @ kh.transpose(-1, -2)) / math.sqrt(dh)
+    pu = torch.exp(sc - sc.amax(dim=-1, keepdim=True))           # un-normalised, max 1 (what the kernel rounds)
+    ao = rnd(((rnd(pu) @ vh) / pu.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(BT, N, D))
     proj = _lin(ao, Wo, bo, rnd)                                    # fp32 accumulators
     sv = emu_adapter(rnd(lam[:, None] * crs), st, pre + "S_Adapter", rnd)   # [BT, D]
     dm = 1.0 if drop_mask is None else drop_mask.reshape(1, N, 1)

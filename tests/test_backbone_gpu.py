@@ -97,7 +97,8 @@ def test_block_against_reference_fixture(golden_dir, T):
     assert _relerr(c["lam"], z["lamda"]) < 1e-2, _relerr(c["lam"], z["lamda"])   # exp() of bf16-rounded q.k
     x_e = z["x"].permute(1, 0, 2).contiguous()
     y_emu, aux = O.emu_block(x_e, st, 0, H, T, 0.5, O.BF16, return_aux=True)
-    assert _maxerr(y, y_emu.reshape(-1, D)) < 3e-3, _maxerr(y, y_emu.reshape(-1, D))
+    assert _relerr(y, y_emu.reshape(-1, D)) < 1e-3, _relerr(y, y_emu.reshape(-1, D))          # 1e-3 (bf16) bar
+    assert _maxerr(y, y_emu.reshape(-1, D)) < 8e-3, _maxerr(y, y_emu.reshape(-1, D))          # <= 2 bf16 ulps at |x|~3
     assert _relerr(c["lam"], aux["lamda"]) < 1e-3
     # backward: dX and the 12 adapter gradients
     def _param(a, leaf):
