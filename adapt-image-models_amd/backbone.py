@@ -256,8 +256,8 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=c["hcat_pre"], act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
              at=c["dms2"], ntok=N)
     ops.wgrad(dcat[:, H4:], c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
-    dxn = _empty((M, D), F32, dev)
-    ops.gemm(dcat, fz.WcatT1, ops.EPI_F32, dxn)      # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
+    dxn = _empty((M, D), BF16, dev)
+    ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
     del dcat
     # ---- ln_2
     dx1, dx1b = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
@@ -292,8 +292,8 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
     ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)
     # ---- fused QKV projection (dgrad) and ln_1
-    dxl = _empty((M, D), F32, dev)
-    ops.gemm(dqkv, fz.WqkvT, ops.EPI_F32, dxl)
+    dxl = _empty((M, D), BF16, dev)
+    ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
     del dqkv
     dx, dxb = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
     ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1, dx=dx,

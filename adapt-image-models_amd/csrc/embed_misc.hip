@@ -170,13 +170,21 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void frame_sum_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ out, int ntok, int D) {
-    const int d = blockIdx.y * 256 + threadIdx.x;
-    if (d >= D) return;
+    const int d4 = blockIdx.y * 256 + threadIdx.x;          // float4 column
+    if (d4 * 4 >= D) return;
     const long long f = blockIdx.x;
-    const float* p = x + f * ntok * (long long)D + d;
-    float acc = 0.f;
-    for (int t = 0; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * p[(long long)t * D];
-    out[f * D + d] = acc;
+    const float* p = x + f * ntok * (long long)D + d4 * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int t = 0;
+    for (; t + 3 < ntok; t += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (long long)(t + u) * D);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (w ? w[t + u] : 1.0f) * v[u];
+    }
+    for (; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * *(const f32x4*)(p + (long long)t * D);
+    *(f32x4*)(out + f * D + d4 * 4) = acc;
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ af,
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // 8 columns per thread (16-byte loads); threads = (C/8 column groups) x (row slots); rows strided by slots
 __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ af,
                                                       const float* __restrict__ at, int ntok, float* __restrict__ out,
-                                                      int M, int C, int rows_per_block) {
+                                                      float* __restrict__ partial, int M, int C, int rows_per_block) {
     const int cg = C >> 3;
     const int nrs = 256 / cg > 0 ? 256 / cg : 1;
     const int t = threadIdx.x;
@@ -212,7 +220,28 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rslot; live && r < r1; r += nrs) {
+    // 4 independent 16-byte loads in flight per thread
+    int r = r0 + rslot;
+    for (; live && r + 3 * nrs < r1; r += 4 * nrs) {
+        bf16x8 v[4];
+        float rs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * nrs;
+            v[u] = *(const bf16x8*)(X + (long long)rr * ldx + col * 8);
+            rs[u] = 1.f;
+            if (af || at) {
+                const int f = rr / ntok, tk = rr - f * ntok;
+                if (af) rs[u] *= af[f];
+                if (at) rs[u] *= at[tk];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += rs[u] * (float)v[u][e];
+    }
+    for (; live && r < r1; r += nrs) {
         float rs = 1.f;
         if (af || at) {
             const int f = r / ntok, tk = r - f * ntok;
@@ -234,9 +263,29 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
         for (int s2 = 1; s2 < nrs; ++s2)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += red[(s2 * cg + col) * 8 + e];
+        if (partial) {       // stage 1 of a two-stage reduction: no atomics, no contention
+            f32x4* p = (f32x4*)(partial + (long long)blockIdx.y * C + col * 8);
+            p[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            p[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(out + col * 8 + e, acc[e]);
+            for (int e = 0; e < 8; ++e) atomicAdd(out + col * 8 + e, acc[e]);
+        }
     }
+}
+
+// stage 2: out[c] += sum_p partial[p][c]; grid (C/64, 16): 64 columns x 4 row-slots per block, 16 blocks per column
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int P, int C) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slot = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int p = blockIdx.y * 4 + slot; p < P; p += gridDim.y * 4) acc += partial[(long long)p * C + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (slot == 0 && c < C) atomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
@@ -382,22 +431,29 @@ extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* 
 }
 
 extern "C" int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream) {
-    AIM_CHECK_ARG(frames > 0 && ntok > 0 && D > 0 && x && out, "frame_sum: bad arguments");
-    hipLaunchKernelGGL(frame_sum_kernel, dim3(frames, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, out, ntok, D);
+    AIM_CHECK_ARG(frames > 0 && ntok > 0 && D > 0 && (D % 4) == 0 && x && out, "frame_sum: bad arguments");
+    hipLaunchKernelGGL(frame_sum_kernel, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, out, ntok, D);
     AIM_CHECK_LAUNCH("aim_frame_sum");
     return 0;
 }
 
 extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok, float* out,
-                               int M, int C, void* stream) {
+                               int M, int C, float* workspace, int64_t workspace_bytes, void* stream) {
     AIM_CHECK_ARG(M > 0 && C > 0 && X && out, "colsum: bad arguments");
     if (af || at) AIM_CHECK_ARG(ntok > 0, "colsum: ntok required with row factors");
     if ((C % 8) == 0 && C <= 2048 && (ldx % 8) == 0) {
-        int rpb8 = (M + 255) / 256;          // <= 256 blocks: one atomic per column per block
+        int rpb8 = (M + 1023) / 1024;        // <= 1024 row blocks
         if (rpb8 < 64) rpb8 = 64;
-        hipLaunchKernelGGL(colsum8_kernel, dim3(1, (M + rpb8 - 1) / rpb8), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)X, ldx, af, at, ntok, out, M, C, rpb8);
+        const int P = (M + rpb8 - 1) / rpb8;
+        // two-stage (partials + finish) when the caller provides scratch; otherwise one atomic per column per block
+        float* partial = (workspace && workspace_bytes >= (int64_t)P * C * 4 && P > 8) ? workspace : nullptr;
+        hipLaunchKernelGGL(colsum8_kernel, dim3(1, P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, af, at,
+                           ntok, out, partial, M, C, rpb8);
         AIM_CHECK_LAUNCH("aim_colsum_bf16");
+        if (partial) {
+            hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, partial, out, P, C);
+            AIM_CHECK_LAUNCH("aim_colsum_bf16(finish)");
+        }
         return 0;
     }
     int rpb = (M + 511) / 512;

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
-template <int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long long lddy,
+template <int NC, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
-            const f32x4 d = *(const f32x4*)(dy + (long long)row * lddy + ch * 4);
+            f32x4 d;
+            if constexpr (sizeof(TDY) == 4) {
+                d = *(const f32x4*)(dy + (long long)row * lddy + ch * 4);
+            } else {
+                const bf16x4 db = *(const bf16x4*)(dy + (long long)row * lddy + ch * 4);
+                d = f32x4{(float)db[0], (float)db[1], (float)db[2], (float)db[3]};
+            }
             const f32x4 xv = *(const f32x4*)(x + (long long)row * ldx + ch * 4);
             const f32x4 gm = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
@@ -142,7 +148,7 @@ extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     return 0;
 }
 
-extern "C" int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, const float* dres, float* dx,
                                  aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int rows, int D,
                                  void* stream) {
@@ -150,10 +156,15 @@ extern "C" int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     AIM_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "layernorm_bwd: null pointer");
     AIM_CHECK_ARG((!dgamma) == (!dbeta), "layernorm_bwd: dgamma and dbeta go together");
     AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
-#define AIM_LN_BWD(NC)                                                                                             \
-    hipLaunchKernelGGL(ln_bwd_kernel<NC>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, (long long)lddy, \
-                       x, (long long)ldx, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, (long long)lddx, dgamma,      \
-                       dbeta, rows, D)
+#define AIM_LN_BWD(NC)                                                                                              \
+    if (dy_is_bf16)                                                                                                 \
+        hipLaunchKernelGGL((ln_bwd_kernel<NC, bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,     \
+                           (const bf16_t*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, dres, dx,        \
+                           (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta, rows, D);                                \
+    else                                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<NC, float>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,       \
+                           (const float*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, dres, dx,          \
+                           (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta, rows, D)
     const int nc = (D + 255) / 256;
     if (nc <= 1) AIM_LN_BWD(1); else if (nc == 2) AIM_LN_BWD(2); else if (nc == 3) AIM_LN_BWD(3);
     else if (nc == 4) AIM_LN_BWD(4); else AIM_LN_BWD(8);

@@ -136,6 +136,6 @@ extern "C" int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, nchunks), dim3(256), 4 * OPER_BYTES, (hipStream_t)stream,
                        (const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, M, Nw, Kw, chunk);
     AIM_CHECK_LAUNCH("aim_wgrad_bf16");
-    if (db) return aim_colsum_bf16(G, ldg, nullptr, nullptr, 0, db, M, Nw, stream);
+    if (db) return aim_colsum_bf16(G, ldg, nullptr, nullptr, 0, db, M, Nw, nullptr, 0, stream);
     return 0;
 }

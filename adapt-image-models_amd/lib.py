@@ -43,7 +43,7 @@ SIGNATURES = {
     "aim_gemm_expsum_tiles": [I, I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
-    "aim_layernorm_bwd": [P, L, P, L, P, P, P, P, P, P, L, P, P, I, I, P],
+    "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, P, P, L, P, P, I, I, P],
     "aim_attn_fwd": [P, P, P, I, I, I, P],
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
@@ -53,7 +53,7 @@ SIGNATURES = {
     "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "aim_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "aim_frame_sum": [P, P, P, I, I, I, P],
-    "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P],
+    "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P, L, P],
     "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
     "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],

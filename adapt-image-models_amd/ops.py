@@ -122,8 +122,10 @@ def wgrad(g: torch.Tensor, a: torch.Tensor, dw: torch.Tensor, db: Optional[torch
     _chk(g, BF16, "g"); _chk(a, BF16, "a"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
     assert g.shape[0] == a.shape[0] and dw.shape == (g.shape[1], a.shape[1])
     check(load_library().aim_wgrad_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(),
-                                        dw.stride(0), _p(db), g.shape[0], g.shape[1], a.shape[1], _stream()),
+                                        dw.stride(0), None, g.shape[0], g.shape[1], a.shape[1], _stream()),
           "aim_wgrad_bf16")
+    if db is not None:
+        colsum(g, db)        # bias gradient through the two-stage (scratch) column sum
 
 
 def layernorm_fwd(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, ldy=None, mean=None, rstd=None,
@@ -137,11 +139,12 @@ def layernorm_fwd(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, ldy=
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=None, dx=None, dx_bf16=None,
                   dgamma=None, dbeta=None):
-    for n_, t_ in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dres", dres),
+    for n_, t_ in (("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dres", dres),
                    ("dx", dx), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t_, F32, n_)
     _chk(dx_bf16, BF16, "dx_bf16")
-    check(load_library().aim_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(),
+    _chk(dy, dy.dtype if dy.dtype in (F32, BF16) else F32, "dy")
+    check(load_library().aim_layernorm_bwd(dy.data_ptr(), int(dy.dtype == BF16), lddy, x.data_ptr(), ldx, gamma.data_ptr(),
                                            mean.data_ptr(), rstd.data_ptr(), _p(dres), _p(dx), _p(dx_bf16), lddx,
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
 
@@ -219,8 +222,12 @@ def frame_sum(x, w, out, frames, ntok, D):
 
 def colsum(X, out, *, af=None, at=None, ntok=0):
     _chk(X, BF16, "X"); _chk(out, F32, "out"); _chk(af, F32, "af"); _chk(at, F32, "at")
+    ws = None
+    if X.shape[0] >= 4096:          # large reductions go two-stage through a scratch buffer (no atomics)
+        ws = torch.empty((1024, X.shape[1]), dtype=F32, device=X.device)
     check(load_library().aim_colsum_bf16(X.data_ptr(), X.stride(0), _p(af), _p(at), ntok, out.data_ptr(),
-                                         X.shape[0], X.shape[1], _stream()), "aim_colsum_bf16")
+                                         X.shape[0], X.shape[1], _p(ws), ws.numel() * 4 if ws is not None else 0,
+                                         _stream()), "aim_colsum_bf16")
 
 
 def cast_bf16(src, dst, transpose=False):

@@ -102,7 +102,8 @@ int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float
 int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                       aim_bf16* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
                       int rows, int D, float eps, void* stream);
-int aim_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0) */, int64_t lddy,
+                      const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* dres, float* dx,
                       aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta,
                       int rows, int D, void* stream);
@@ -165,7 +166,8 @@ int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const 
  * ------------------------------------------------------------------------------------------ */
 int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream);
 int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok,
-                    float* out, int M, int C, void* stream);
+                    float* out, int M, int C, float* workspace /* optional: >= 1024*C floats -> two-stage, no atomics */,
+                    int64_t workspace_bytes, void* stream);
 int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, int ldd /* dst row stride, 0 = dense */,
                   void* stream);
 int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
