@@ -52,9 +52,13 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 }
 
 // QuickGELU x*sigmoid(1.702x) (reference vit_clip.py:80-82) and its derivative
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// sigmoid through v_exp_f32 (base 2) + v_rcp_f32: no IEEE division sequence in the GEMM epilogues
+__device__ __forceinline__ float sigmoid_1702(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoid_1702(x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    const float s = sigmoid_1702(x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 // exact erf GELU (nn.GELU(), reference vit_clip.py:52) and its derivative

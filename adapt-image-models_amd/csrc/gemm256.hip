@@ -19,52 +19,88 @@
 // counted wait that retired it.  WAR: a half-tile is re-staged one phase after its last ds_read, whose
 // lgkmcnt(0) precedes that phase's closing barrier.  Tiles past K are staged with out-of-range
 // offsets (zero fill, still counted by vmcnt) so the counts are uniform.
+//
+// The kernel is PERSISTENT (one workgroup per CU walks the tiles): the look-ahead of the staging schedule runs
+// across tile boundaries, so only the very first tile of a workgroup pays a prologue, and the epilogue
+// (re-tiled through a wave-private 2 KiB LDS scratch beside the images) overlaps the next tile's loads.
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
 #include "gemm_epilogue.h"
 #include <stdlib.h>
+
+static int aim_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
+}
 
 namespace {
 
 constexpr int HT = 128 * 64 * 2;        // half-tile bytes
 constexpr int BUF = 4 * HT;             // one K-tile buffer: A_lo, A_hi, B_lo, B_hi
 constexpr int OFF_A = 0, OFF_B = 2 * HT;
+constexpr int LDS_BYTES = 2 * BUF + 8 * EPI_SCRATCH;   // K-loop images + 8 wave-private epilogue scratches
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
+// Per-tile staging state: buffer descriptors of the tile's A rows / W rows and the per-lane row offsets.
+struct TileSrc {
+    __amdgpu_buffer_rsrc_t rA, rW;
+    unsigned voA[2][2], voW[2][2];   // [half][piece]; AIM_OOB for rows past M / N
+    int m0, n0;
+};
 
-    const int tiles_n = (g.N + 255) >> 8;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    const bf16_t* Ab = (const bf16_t*)g.A + (long long)m0 * g.lda;
-    const bf16_t* Wb = (const bf16_t*)g.W + (long long)n0 * g.ldw;
-    const int rowsA = g.M - m0, rowsW = g.N - n0;
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab, ((long long)(rowsA - 1) * g.lda + g.K) * 2);
-    const __amdgpu_buffer_rsrc_t rW = make_rsrc(Wb, ((long long)(rowsW - 1) * g.ldw + g.K) * 2);
-
-    // staging constants: half-tile = 16 pieces of 8 rows; wave stages pieces 2*wave, 2*wave+1
-    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    unsigned voA[2][2], voW[2][2];   // [half][piece]
+__device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int ntiles, int tiles_n, int wave, int srow,
+                                             int schunk) {
+    TileSrc t;
+    const bool live = tile < ntiles;
+    const int tn = live ? tile % tiles_n : 0, tm = live ? tile / tiles_n : 0;
+    t.m0 = tm * 256;
+    t.n0 = tn * 256;
+    const int rowsA = live ? g.M - t.m0 : 0, rowsW = live ? g.N - t.n0 : 0;
+    const bf16_t* Ab = (const bf16_t*)g.A + (long long)t.m0 * g.lda;
+    const bf16_t* Wb = (const bf16_t*)g.W + (long long)t.n0 * g.ldw;
+    t.rA = make_rsrc(Ab, live ? ((long long)(rowsA - 1) * g.lda + g.K) * 2 : 0);
+    t.rW = make_rsrc(Wb, live ? ((long long)(rowsW - 1) * g.ldw + g.K) * 2 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = h * 128 + (wave * 2 + j) * 8 + srow;
-            voA[h][j] = r < rowsA ? (unsigned)((r * g.lda + schunk * 8) * 2) : AIM_OOB;
-            voW[h][j] = r < rowsW ? (unsigned)((r * g.ldw + schunk * 8) * 2) : AIM_OOB;
+            t.voA[h][j] = r < rowsA ? (unsigned)((r * g.lda + schunk * 8) * 2) : AIM_OOB;
+            t.voW[h][j] = r < rowsW ? (unsigned)((r * g.ldw + schunk * 8) * 2) : AIM_OOB;
         }
-    const int nk = (g.K + 63) >> 6;
+    return t;
+}
 
-    // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi
-    auto stage = [&](int buf, int which, int kt) {
+// Persistent: gridDim.x workgroups (one per CU) walk the output tiles  tile = logical_id + i * gridDim.x.
+// The staging pipeline never drains at a tile boundary: a tile occupies nkp = 2*ceil(nk/2) K-slots and
+// the schedule's look-ahead (up to 3 K-tiles) simply runs into the NEXT tile's first K-tiles, so its
+// prologue latency is hidden behind this tile's last MFMAs and its epilogue.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
+    AIM_LDS char* escr = smem + 2 * BUF;          // epilogue scratch lives beside the K-loop images
+
+    const int tiles_n = (g.N + 255) >> 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const int nk = (g.K + 63) >> 6;
+    const int nkp = (nk + 1) & ~1;               // K-slots per tile (even)
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    TileSrc cur = make_tile(g, tile, ntiles, tiles_n, wave, srow, schunk);
+    TileSrc nxt = make_tile(g, tile + gridDim.x, ntiles, tiles_n, wave, srow, schunk);
+
+    // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
+    auto stage = [&](int buf, int which, int slot) {
+        const bool in_next = slot >= nkp;
+        const int kt = in_next ? slot - nkp : slot;
         const int k0 = kt * 64;
         const bool kin = (k0 + schunk * 8) < g.K;
         AIM_LDS char* dst = smem + buf * BUF + which * HT + wave * 2048;
@@ -72,20 +108,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (which < 2) {
-                const unsigned v = (kin && voA[h][j] != AIM_OOB) ? voA[h][j] + (unsigned)(k0 * 2) : AIM_OOB;
-                stage_piece(rA, dst + j * 1024, v);
+                const unsigned vo = in_next ? nxt.voA[h][j] : cur.voA[h][j];
+                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * 2) : AIM_OOB;
+                stage_piece(in_next ? nxt.rA : cur.rA, dst + j * 1024, v);
             } else {
-                const unsigned v = (kin && voW[h][j] != AIM_OOB) ? voW[h][j] + (unsigned)(k0 * 2) : AIM_OOB;
-                stage_piece(rW, dst + j * 1024, v);
+                const unsigned vo = in_next ? nxt.voW[h][j] : cur.voW[h][j];
+                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * 2) : AIM_OOB;
+                stage_piece(in_next ? nxt.rW : cur.rW, dst + j * 1024, v);
             }
         }
     };
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], bfr[4][2];
 
     auto read_b = [&](int buf) {
@@ -119,81 +153,81 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #define AIM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define AIM_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 
-    // prologue: tile 0 complete, three half-tiles of tile 1 in flight
+    // prologue (first tile only): K-tile 0 complete, three half-tiles of K-tile 1 in flight
     stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);
     stage(1, 2, 1); stage(1, 3, 1); stage(1, 0, 1);
     AIM_VM6();
     AIM_BAR();
 
-    const int niter = (nk + 1) >> 1;
-    for (int it = 0; it < niter; ++it) {
-        const int te = 2 * it, to = te + 1;
-        const bool odd_live = to < nk;
-        // ---- even tile (buffer 0) ----
-        read_b(0); read_a(0, 0);
-        stage(1, 1, to);
-        AIM_BAR(); AIM_LGKM0();
-        mma(0, 0);
-        AIM_BAR();
-        // phase 2
-        stage(0, 2, te + 2);
-        AIM_BAR();
-        mma(0, 2);
-        AIM_BAR();
-        // phase 3
-        read_a(0, 1);
-        stage(0, 3, te + 2);
-        AIM_BAR(); AIM_LGKM0();
-        mma(1, 2);
-        AIM_BAR();
-        // phase 4
-        stage(0, 0, te + 2);
-        AIM_VM6();
-        AIM_BAR();
-        mma(1, 0);
-        AIM_BAR();
-        // ---- odd tile (buffer 1) ----
-        if (odd_live) { read_b(1); read_a(1, 0); }
-        stage(0, 1, te + 2);
-        AIM_BAR(); AIM_LGKM0();
-        if (odd_live) mma(0, 0);
-        AIM_BAR();
-        // phase 6
-        stage(1, 2, to + 2);
-        AIM_BAR();
-        if (odd_live) mma(0, 2);
-        AIM_BAR();
-        // phase 7
-        if (odd_live) read_a(1, 1);
-        stage(1, 3, to + 2);
-        AIM_BAR(); AIM_LGKM0();
-        if (odd_live) mma(1, 2);
-        AIM_BAR();
-        // phase 8
-        stage(1, 0, to + 2);
-        AIM_VM6();
-        AIM_BAR();
-        if (odd_live) mma(1, 0);
-        AIM_BAR();
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int it = 0; it < nkp / 2; ++it) {
+            const int te = 2 * it, to = te + 1;
+            const bool odd_live = to < nk;
+            // ---- even K-tile (buffer 0) ----
+            read_b(0); read_a(0, 0);
+            stage(1, 1, to);
+            AIM_BAR(); AIM_LGKM0();
+            mma(0, 0);
+            AIM_BAR();
+            stage(0, 2, te + 2);                    // phase 2
+            AIM_BAR();
+            mma(0, 2);
+            AIM_BAR();
+            read_a(0, 1);                           // phase 3
+            stage(0, 3, te + 2);
+            AIM_BAR(); AIM_LGKM0();
+            mma(1, 2);
+            AIM_BAR();
+            stage(0, 0, te + 2);                    // phase 4
+            AIM_VM6();
+            AIM_BAR();
+            mma(1, 0);
+            AIM_BAR();
+            // ---- odd K-tile (buffer 1) ----
+            if (odd_live) { read_b(1); read_a(1, 0); }
+            stage(0, 1, te + 2);
+            AIM_BAR(); AIM_LGKM0();
+            if (odd_live) mma(0, 0);
+            AIM_BAR();
+            stage(1, 2, to + 2);                    // phase 6
+            AIM_BAR();
+            if (odd_live) mma(0, 2);
+            AIM_BAR();
+            if (odd_live) read_a(1, 1);             // phase 7
+            stage(1, 3, to + 2);
+            AIM_BAR(); AIM_LGKM0();
+            if (odd_live) mma(1, 2);
+            AIM_BAR();
+            stage(1, 0, to + 2);                    // phase 8
+            AIM_VM6();
+            AIM_BAR();
+            if (odd_live) mma(1, 0);
+            AIM_BAR();
+        }
+        // Epilogue of this tile; the next tile's first K-tiles are already in flight / landed in the K-loop
+        // images, so the scratch is separate (wave-private, no barrier needed).
+        wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
+        cur = nxt;
+        nxt = make_tile(g, tile + 2 * gridDim.x, ntiles, tiles_n, wave, srow, schunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
-
-    // ---- epilogue through LDS: re-tile each wave's 128x64 block so that a wave-instruction covers
-    // 4 rows x 64 consecutive columns (16 lanes x 4 columns per row): residual / aux loads and the
-    // output stores are then whole 128-256 B lines instead of 8-16 B fragments per lane.
-    AIM_BAR();                                    // every wave is done reading the K-loop images
-    wave_epilogue<EPI>(g, acc, smem + wave * EPI_SCRATCH, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 template <int EPI>
 int launch256(const GemmArgs& g, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles), dim3(512), 2 * BUF, st, g);
+    const int grid = tiles < aim_num_cus() ? tiles : aim_num_cus();
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }

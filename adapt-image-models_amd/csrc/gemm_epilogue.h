@@ -138,8 +138,7 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 // stores) and keeps two row-blocks of loads in flight.  Column-only inputs (bias) are loaded once.
 // ------------------------------------------------------------------------------------------------
 constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad
-constexpr int EPI_ROWS = 32;                     // rows per pass (two 16-row MFMA tiles)
-constexpr int EPI_SCRATCH = EPI_ROWS * EPI_RS;   // bytes per wave
+constexpr int EPI_SCRATCH = 8 * EPI_RS;          // bytes per wave: 8 rows at a time (fits beside the K-loop images)
 
 template <int EPI>
 struct RowIn {       // memory-side inputs of one (row, lane) 4-column fragment
@@ -151,12 +150,15 @@ template <int EPI>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base,
                                               int n_base, int lane) {
     const int frow = lane & 15, fq = lane >> 4;
-    auto dump = [&](int p) {       // two MFMA row-tiles -> scratch rows 0..31
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+    // half of one 16-row MFMA tile -> scratch rows 0..7 (the lanes holding the other half sit out)
+    auto dump8 = [&](int mt, int half) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // previous sub-pass's scratch reads are done (WAR)
+        if ((frow >> 3) == half) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(AIM_LDS f32x4*)(scr + (ii * 16 + frow) * EPI_RS + (j * 16 + fq * 4) * 4) = acc[p * 2 + ii][j];
+                *(AIM_LDS f32x4*)(scr + (frow & 7) * EPI_RS + (j * 16 + fq * 4) * 4) = acc[mt][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // writes landed before other lanes read them
     };
     const bool rowf = g.af || g.at || g.vec;
     if constexpr (EPI == EPI_BF16) {
@@ -170,32 +172,28 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             if (n + 4 < g.N) b1 = *(const f32x4*)(g.bias + n + 4);
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            dump(p);
+        for (int p = 0; p < 16; ++p) {          // 16 sub-passes of 8 rows
+            dump8(p >> 1, p & 1);
+            f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4);
+            f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4 + 16);
+            const int m = m_base + p * 8 + r8;
+            if (m >= g.M || n >= g.N) continue;
+            float rs = 1.0f;
+            if (rowf) rs = row_factors(g, m).rs;
+            v0 = (v0 + b0) * rs;
+            v1 = (v1 + b1) * rs;
+            bf16_t* o = (bf16_t*)g.out + (long long)m * g.ldo + n;
+            if (wide) {
+                bf16x8 w;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = t * 8 + r8;
-                f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + c8 * 4);
-                f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + c8 * 4 + 16);
-                const int m = m_base + p * 32 + r;
-                if (m >= g.M || n >= g.N) continue;
-                float rs = 1.0f;
-                if (rowf) rs = row_factors(g, m).rs;
-                v0 = (v0 + b0) * rs;
-                v1 = (v1 + b1) * rs;
-                bf16_t* o = (bf16_t*)g.out + (long long)m * g.ldo + n;
-                if (wide) {
-                    bf16x8 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        w[e] = (bf16_t)v0[e];
-                        w[4 + e] = (bf16_t)v1[e];
-                    }
-                    *(bf16x8*)o = w;
-                } else {
-                    *(bf16x4*)o = pack4(v0[0], v0[1], v0[2], v0[3]);
-                    if (n + 4 < g.N) *(bf16x4*)(o + 4) = pack4(v1[0], v1[1], v1[2], v1[3]);
+                for (int e = 0; e < 4; ++e) {
+                    w[e] = (bf16_t)v0[e];
+                    w[4 + e] = (bf16_t)v1[e];
                 }
+                *(bf16x8*)o = w;
+            } else {
+                *(bf16x4*)o = pack4(v0[0], v0[1], v0[2], v0[3]);
+                if (n + 4 < g.N) *(bf16x4*)(o + 4) = pack4(v1[0], v1[1], v1[2], v1[3]);
             }
         }
     } else {
@@ -207,11 +205,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         const int act = col_act(g, n);
         const bool rs_on = !(EPI == EPI_ACT || EPI == EPI_DACT) || g.n_split == 0 || n >= g.n_split;
         constexpr bool HAS_IN = (EPI == EPI_F32 || EPI == EPI_DACT);
-        auto load_rows = [&](int p, RowIn<EPI> (&ri)[8]) {
+        // group = 32 rows (two MFMA row-tiles): 8 rows per lane, rows t*4 + rr of the group
+        auto load_rows = [&](int grp, RowIn<EPI> (&ri)[8]) {
             if constexpr (HAS_IN) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int m = m_base + p * 32 + t * 4 + rr;
+                    const int m = m_base + grp * 32 + t * 4 + rr;
                     ri[t].resid = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (m < g.M && ncol) {
                         if constexpr (EPI == EPI_F32) {
@@ -223,49 +222,53 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 }
             }
         };
-        auto finish = [&](int p, const RowIn<EPI> (&ri)[8]) {
+        auto finish = [&](int grp, const RowIn<EPI> (&ri)[8]) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int r = t * 4 + rr;
-                f32x4 v = *(const AIM_LDS f32x4*)(scr + r * EPI_RS + cc * 4);
-                const int m = m_base + p * 32 + r;
-                if (m >= g.M || !ncol) continue;
-                RowFactors rf{1.0f, 0.0f, 0};
-                if (rowf && rs_on) rf = row_factors(g, m);
-                const float rs = rf.rs;
-                if (EPI == EPI_F32 && g.rs_bias_only) v += rs * bias4; else v += bias4;
-                if constexpr (EPI == EPI_ACT) {
-                    const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
-                    *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
-                    float a[4];
+            for (int sp = 0; sp < 4; ++sp) {      // sub-pass: group rows 8*sp .. 8*sp+7
+                dump8(grp * 2 + (sp >> 1), sp & 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = (float)pre[e];
-                        a[e] = rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = sp * 2 + tt;
+                    f32x4 v = *(const AIM_LDS f32x4*)(scr + (tt * 4 + rr) * EPI_RS + cc * 4);
+                    const int m = m_base + grp * 32 + t * 4 + rr;
+                    if (m >= g.M || !ncol) continue;
+                    RowFactors rf{1.0f, 0.0f, 0};
+                    if (rowf && rs_on) rf = row_factors(g, m);
+                    const float rs = rf.rs;
+                    if (EPI == EPI_F32 && g.rs_bias_only) v += rs * bias4; else v += bias4;
+                    if constexpr (EPI == EPI_ACT) {
+                        const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
+                        *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+                        float a[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = (float)pre[e];
+                            a[e] = rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
+                        }
+                        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
+                    } else if constexpr (EPI == EPI_DACT) {
+                        float a[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = (float)ri[t].aux[e];
+                            a[e] = rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
+                        }
+                        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
+                    } else {   // EPI_F32
+                        if (!g.rs_bias_only) v *= rs;
+                        if (g.vec) v += rf.vs * *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
+                        v += ri[t].resid;
+                        *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
                     }
-                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
-                } else if constexpr (EPI == EPI_DACT) {
-                    float a[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = (float)ri[t].aux[e];
-                        a[e] = rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
-                    }
-                    *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
-                } else {   // EPI_F32
-                    if (!g.rs_bias_only) v *= rs;
-                    if (g.vec) v += rf.vs * *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
-                    v += ri[t].resid;
-                    *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
                 }
             }
         };
-        // loads of pass p+1 are issued before the stores of pass p: a wave never waits on a store ack
+        // loads of group p+1 are issued before the stores of group p: a wave never waits on a store ack
         RowIn<EPI> ra[8], rb[8];
         load_rows(0, ra);
-        dump(0); load_rows(1, rb); finish(0, ra);
-        dump(1); load_rows(2, ra); finish(1, rb);
-        dump(2); load_rows(3, rb); finish(2, ra);
-        dump(3); finish(3, rb);
+        load_rows(1, rb); finish(0, ra);
+        load_rows(2, ra); finish(1, rb);
+        load_rows(3, rb); finish(2, ra);
+        finish(3, rb);
     }
 }
