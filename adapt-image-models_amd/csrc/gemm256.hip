@@ -79,7 +79,7 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
 // the schedule's look-ahead (up to 3 K-tiles) simply runs into the NEXT tile's first K-tiles, so its
 // prologue latency is hidden behind this tile's last MFMAs and its epilogue.
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles) {
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
     AIM_LDS char* escr = smem + 2 * BUF;          // epilogue scratch lives beside the K-loop images
@@ -93,9 +93,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles) {
     const int nk = (g.K + 63) >> 6;
     const int nkp = (nk + 1) & ~1;               // K-slots per tile (even)
 
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    TileSrc cur = make_tile(g, tile, ntiles, tiles_n, wave, srow, schunk);
-    TileSrc nxt = make_tile(g, tile + gridDim.x, ntiles, tiles_n, wave, srow, schunk);
+    // ---- tile schedule: column groups per XCD ---------------------------------------------------
+    // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD; speed only, never
+    // correctness).  The weight matrix is cut into `ngroups` column groups whose slice fits an XCD's
+    // 4 MiB L2 together with the streaming A tiles; XCD x serves group x % ngroups for its share of the
+    // row blocks, walking them column-fastest so the CUs of an XCD share A rows at any moment.
+    //   seq = i * wg_per_group + rank   ->   (tm, tn) = (seq / ncols, c0 + seq % ncols)
+    const bool grouped = (gridDim.x & 7) == 0;                    // otherwise: one group, plain round-robin
+    const int ng = grouped ? ngroups : 1;
+    const int xcd = grouped ? (int)(blockIdx.x & 7) : 0;
+    const int in_xcd = grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int per_xcd = grouped ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int grp = xcd % ng;
+    const int cpg = (tiles_n + ng - 1) / ng;                      // columns per group
+    const int c0 = grp * cpg;
+    const int ncols = min(cpg, tiles_n - c0);                     // may be <= 0 for a trailing empty group
+    const int rank = (xcd / ng) * per_xcd + in_xcd;               // XCD-major inside the group
+    const int wg_per_group = grouped ? (8 / ng) * per_xcd : (int)gridDim.x;
+    const int tiles_m = (g.M + 255) >> 8;
+    const int nseq = ncols > 0 ? tiles_m * ncols : 0;
+    auto seq_tile = [&](int seq) { return seq < nseq ? (seq / ncols) * tiles_n + c0 + seq % ncols : ntiles; };
+    int seq = rank;
+    TileSrc cur = make_tile(g, seq_tile(seq), ntiles, tiles_n, wave, srow, schunk);
+    TileSrc nxt = make_tile(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, wave, srow, schunk);
 
     // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
     auto stage = [&](int buf, int which, int slot) {
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles) {
     AIM_VM6();
     AIM_BAR();
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; seq < nseq; seq += wg_per_group) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles) {
         // images, so the scratch is separate (wave-private, no barrier needed).
         wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
         cur = nxt;
-        nxt = make_tile(g, tile + 2 * gridDim.x, ntiles, tiles_n, wave, srow, schunk);
+        nxt = make_tile(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, wave, srow, schunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }
@@ -226,8 +246,18 @@ int launch256(const GemmArgs& g, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const int grid = tiles < aim_num_cus() ? tiles : aim_num_cus();
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles);
+    int grid = tiles < aim_num_cus() ? tiles : aim_num_cus();
+    // column groups: keep each group's weight slice (+ streaming A) inside an XCD's 4 MiB L2
+    int ngroups = 1;
+    static const int force_groups = [] { const char* e = getenv("AIM_GEMM_GROUPS"); return e ? atoi(e) : 0; }();
+    if (grid >= 64 && (grid % 8) == 0) {
+        // measured on MI355X: <= 4 % gain on N >= 3072 and a loss whenever the groups are unbalanced, so the
+        // default is one group; AIM_GEMM_GROUPS = 2 | 4 | 8 is kept for experiments
+        if (force_groups == 2 || force_groups == 4 || force_groups == 8) ngroups = force_groups;
+    } else if (grid >= 8) {
+        grid = (grid / 8) * 8;     // XCD-aware schedule wants a multiple of 8; smaller grids use plain round-robin
+    }
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, ngroups);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }
