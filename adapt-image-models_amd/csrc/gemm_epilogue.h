@@ -161,41 +161,95 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // writes landed before other lanes read them
     };
     const bool rowf = g.af || g.at || g.vec;
-    if constexpr (EPI == EPI_BF16) {
-        // 8 lanes x 8 columns per row, 8 rows per wave-instruction, 16-byte stores, no memory inputs but bias
+    if constexpr (EPI != EPI_F32) {
+        // bf16 outputs (BF16 / ACT / DACT): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
+        // global access is a 16-byte-per-lane, whole-128-B-row-segment instruction (the 8-byte form is
+        // store-issue-bound).  DACT's saved pre-activations are prefetched one 32-row group ahead.
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
         const int n = n_base + c8;
-        const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N;
+        const bool ncol = n < g.N;
+        const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N && (EPI != EPI_ACT || (g.ldo2 % 8) == 0) &&
+                          (EPI != EPI_DACT || (g.ldaux % 8) == 0);
         f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (g.bias && n < g.N) {
+        if (g.bias && ncol) {
             b0 = *(const f32x4*)(g.bias + n);
             if (n + 4 < g.N) b1 = *(const f32x4*)(g.bias + n + 4);
         }
+        const int act = col_act(g, n);
+        const bool rs_on = EPI == EPI_BF16 || g.n_split == 0 || n >= g.n_split;
+        auto load_aux = [&](int grp, bf16x8 (&ax)[4]) {
+            if constexpr (EPI == EPI_DACT) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {          // 16 sub-passes of 8 rows
-            dump8(p >> 1, p & 1);
-            f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4);
-            f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4 + 16);
-            const int m = m_base + p * 8 + r8;
-            if (m >= g.M || n >= g.N) continue;
-            float rs = 1.0f;
-            if (rowf) rs = row_factors(g, m).rs;
-            v0 = (v0 + b0) * rs;
-            v1 = (v1 + b1) * rs;
-            bf16_t* o = (bf16_t*)g.out + (long long)m * g.ldo + n;
-            if (wide) {
-                bf16x8 w;
+                for (int t = 0; t < 4; ++t) {
+                    const int m = m_base + grp * 32 + t * 8 + r8;
+                    if (m < g.M && ncol) {
+                        const bf16_t* ap = (const bf16_t*)g.aux + (long long)m * g.ldaux + n;
+                        if (wide) {
+                            ax[t] = *(const bf16x8*)ap;
+                        } else {
+                            const bf16x4 lo = *(const bf16x4*)ap;
+                            bf16x4 hi = lo;
+                            if (n + 4 < g.N) hi = *(const bf16x4*)(ap + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    w[e] = (bf16_t)v0[e];
-                    w[4 + e] = (bf16_t)v1[e];
+                            for (int e = 0; e < 4; ++e) { ax[t][e] = lo[e]; ax[t][4 + e] = hi[e]; }
+                        }
+                    }
                 }
-                *(bf16x8*)o = w;
-            } else {
-                *(bf16x4*)o = pack4(v0[0], v0[1], v0[2], v0[3]);
-                if (n + 4 < g.N) *(bf16x4*)(o + 4) = pack4(v1[0], v1[1], v1[2], v1[3]);
             }
-        }
+        };
+        auto finish8 = [&](int grp, const bf16x8 (&ax)[4]) {
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                dump8(grp * 2 + (sp >> 1), sp & 1);
+                const f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4);
+                const f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4 + 16);
+                const int m = m_base + grp * 32 + sp * 8 + r8;
+                if (m >= g.M || !ncol) continue;
+                float rs = 1.0f;
+                if (rowf && rs_on) rs = row_factors(g, m).rs;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+                bf16x8 o, pre;
+                if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rs * v[e]);
+                } else if constexpr (EPI == EPI_ACT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pre[e] = (bf16_t)v[e];
+                        const float x = (float)pre[e];
+                        o[e] = (bf16_t)(rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x)));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)ax[sp][e];
+                        o[e] = (bf16_t)(rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x)));
+                    }
+                }
+                bf16_t* op = (bf16_t*)g.out + (long long)m * g.ldo + n;
+                if (wide) {
+                    *(bf16x8*)op = o;
+                    if constexpr (EPI == EPI_ACT) *(bf16x8*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+                } else {       // ragged N / odd strides: two 4-column halves
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        if (n + 4 * hh >= g.N) break;
+                        *(bf16x4*)(op + 4 * hh) = bf16x4{o[4 * hh], o[4 * hh + 1], o[4 * hh + 2], o[4 * hh + 3]};
+                        if constexpr (EPI == EPI_ACT)
+                            *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n + 4 * hh) =
+                                bf16x4{pre[4 * hh], pre[4 * hh + 1], pre[4 * hh + 2], pre[4 * hh + 3]};
+                    }
+                }
+            }
+        };
+        bf16x8 xa[4], xb[4];
+        load_aux(0, xa);
+        load_aux(1, xb); finish8(0, xa);
+        load_aux(2, xa); finish8(1, xb);
+        load_aux(3, xb); finish8(2, xa);
+        finish8(3, xb);
     } else {
         const int rr = lane >> 4, cc = (lane & 15) * 4;
         const int n = n_base + cc;
