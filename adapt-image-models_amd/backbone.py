@@ -12,6 +12,7 @@ There is no eager/CPU fallback: ``forward`` raises unless the input is on a GPU 
 library is built.
 """
 import logging
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
@@ -154,6 +155,47 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+# The class-token path of a block (temporal attention, T_/S_Adapter, the cross term: a dozen GEMMs on
+# B*T = 512 rows) occupies a few CUs for ~100 us.  It runs on a second HIP stream beside the spatial
+# attention kernels, which do not depend on it; the two are joined with events before `lamda`.
+_SIDE = {}
+_USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
+
+
+class _Fork:
+    """``with _Fork(dev) as f:`` runs the body on the side stream after everything queued on the current
+    stream so far; ``f.join()`` makes the current stream wait for the body."""
+
+    def __init__(self, dev):
+        self.enabled = _USE_SIDE
+        if self.enabled:
+            key = (dev.type, dev.index)
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=dev)
+            self.side = _SIDE[key]
+            self.main = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_event(self.done)
+
+
 # ----------------------------------------------------------------------------------------------
 # one block: forward / backward on raw buffers
 # ----------------------------------------------------------------------------------------------
@@ -179,29 +221,32 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     qkv = _empty((M, 3 * D), BF16, dev)
     ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
     del xl
-    # temporal attention over the class tokens + T_Adapter (vit_clip.py:220-229)
-    ot = _empty((BT, D), BF16, dev)
-    probs = _empty((B, H, T, T), F32, dev)
-    ops.cls_attn_fwd(qkv, ot, probs, B, T, N, H)
-    ta = _empty((BT, D), BF16, dev)
-    ops.gemm(ot, fz.Wo, ops.EPI_BF16, ta, bias=fz.bo)
-    xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, dev, out_f32=False)
-    # cross-attention to the single key/value xt[bt] (:265): softmax == 1, so crs = out_proj(W_v xt + b_v)
-    kv = _empty((BT, 2 * D), BF16, dev)
-    ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
-    crs = _empty((BT, D), F32, dev)
-    ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
-    # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
+    # temporal attention over the class tokens + T_Adapter (vit_clip.py:220-229), then the cross term;
+    # on the side stream, concurrent with the spatial attention below
+    with _Fork(dev) as fork:
+        ot = _empty((BT, D), BF16, dev)
+        probs = _empty((B, H, T, T), F32, dev)
+        ops.cls_attn_fwd(qkv, ot, probs, B, T, N, H)
+        ta = _empty((BT, D), BF16, dev)
+        ops.gemm(ot, fz.Wo, ops.EPI_BF16, ta, bias=fz.bo)
+        xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, dev, out_f32=False)
+        # cross-attention to the single key/value xt[bt] (:265): softmax == 1, so crs = out_proj(W_v xt + b_v)
+        kv = _empty((BT, 2 * D), BF16, dev)
+        ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
+        crs = _empty((BT, D), F32, dev)
+        ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
+    # spatial attention (:264) and the ow statistic of lamda (:149-151) -- independent of the class-token path
+    ao = _empty((M, D), BF16, dev)
+    lse = _empty((BT, H, N), F32, dev)
+    ops.attn_fwd(qkv, ao, lse, BT, N, H)
     nt = ops.expsum_tiles(N, N)
     part = _empty((BT, nt, 2), F32, dev)
     ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
              stride_w=N * 3 * D, scale=0.125)
+    fork.join()
+    # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
     lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
     ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125)
-    # spatial attention (:264)
-    ao = _empty((M, D), BF16, dev)
-    lse = _empty((BT, H, N), F32, dev)
-    ops.attn_fwd(qkv, ao, lse, BT, N, H)
     # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
     sin = _empty((BT, D), BF16, dev)
     ops.scale_rows(crs, lam, y=sin)
@@ -265,8 +310,27 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
                       dx_bf16=dx1b)
     del dxn
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
-    dsv = _empty((BT, D), F32, dev)
-    ops.frame_sum(dx1, c["dms1"], dsv, BT, N, D)
+    # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
+    with _Fork(dev) as fork:
+        dsv = _empty((BT, D), F32, dev)
+        ops.frame_sum(dx1, c["dms1"], dsv, BT, N, D)
+        # S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
+        dsv_b = _empty((BT, D), BF16, dev)
+        ops.cast_bf16(dsv, dsv_b)
+        dsin = _adapter_bwd_small(dsv_b, adp["S_Adapter"], c["sin"], c["s_pre"], c["s_h"], grads["S_Adapter"], BT, r,
+                                  D, dev, need_dx_bf16=False)
+        dcrs = _empty((BT, D), BF16, dev)
+        ops.scale_rows(dsin, c["lam"], y=dcrs)
+        dvx = _empty((BT, D), BF16, dev)
+        ops.gemm(dcrs, fz.WoT, ops.EPI_BF16, dvx)
+        dxt = _empty((BT, D), BF16, dev)
+        ops.gemm(dvx, fz.WqkvT[:, 2 * D:], ops.EPI_BF16, dxt)
+        # T_Adapter and out_proj of the temporal attention over class tokens
+        dta = _adapter_bwd_small(dxt, adp["T_Adapter"], c["ta"], c["t_pre"], c["t_h"], grads["T_Adapter"], BT, r, D,
+                                 dev, need_dx_bf16=True)
+        dot = _empty((BT, D), BF16, dev)
+        ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
+    # ... beside the spatial attention backward on the main stream
     dao = _empty((M, D), BF16, dev)
     ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N)
     del dx1b
@@ -274,23 +338,8 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     delta = _empty((BT, H, N), F32, dev)
     ops.attn_bwd(c["qkv"], c["ao"], dao, c["lse"], delta, dqkv, BT, N, H)
     del dao
-    # ---- S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
-    dsv_b = _empty((BT, D), BF16, dev)
-    ops.cast_bf16(dsv, dsv_b)
-    dsin = _adapter_bwd_small(dsv_b, adp["S_Adapter"], c["sin"], c["s_pre"], c["s_h"], grads["S_Adapter"], BT, r, D,
-                              dev, need_dx_bf16=False)
-    dcrs = _empty((BT, D), BF16, dev)
-    ops.scale_rows(dsin, c["lam"], y=dcrs)
-    dvx = _empty((BT, D), BF16, dev)
-    ops.gemm(dcrs, fz.WoT, ops.EPI_BF16, dvx)
-    dxt = _empty((BT, D), BF16, dev)
-    ops.gemm(dvx, fz.WqkvT[:, 2 * D:], ops.EPI_BF16, dxt)
-    # ---- T_Adapter and the temporal attention over class tokens
-    dta = _adapter_bwd_small(dxt, adp["T_Adapter"], c["ta"], c["t_pre"], c["t_h"], grads["T_Adapter"], BT, r, D, dev,
-                             need_dx_bf16=True)
-    dot = _empty((BT, D), BF16, dev)
-    ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
-    ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)
+    fork.join()
+    ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)     # adds the class rows' dq/dk/dv
     # ---- fused QKV projection (dgrad) and ln_1
     dxl = _empty((M, D), BF16, dev)
     ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
