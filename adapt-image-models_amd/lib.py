@@ -41,7 +41,8 @@ SIGNATURES = {
     "aim_last_error": [],
     "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
     "aim_gemm_expsum_tiles": [I, I],
-    "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P],
+    "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
+    "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
     "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, P, P, L, P, P, I, I, P],
     "aim_attn_fwd": [P, P, P, I, I, I, P],
@@ -76,7 +77,7 @@ def load_library():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "aim_last_error" else c_int
+        fn.restype = c_char_p if name == "aim_last_error" else (c_int64 if name.endswith("_bytes") else c_int)
     if lib.aim_version() != ABI_VERSION:
         raise LibraryNotBuilt(f"{path}: ABI version {lib.aim_version()} != {ABI_VERSION}; rebuild")
     _LIB = lib

@@ -121,9 +121,11 @@ def wgrad(g: torch.Tensor, a: torch.Tensor, dw: torch.Tensor, db: Optional[torch
     """``dw[n,k] += sum_m g[m,n] a[m,k]``; ``db[n] += sum_m g[m,n]`` (fp32 accumulate in place)."""
     _chk(g, BF16, "g"); _chk(a, BF16, "a"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
     assert g.shape[0] == a.shape[0] and dw.shape == (g.shape[1], a.shape[1])
-    check(load_library().aim_wgrad_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(),
-                                        dw.stride(0), None, g.shape[0], g.shape[1], a.shape[1], _stream()),
-          "aim_wgrad_bf16")
+    lib = load_library()
+    nbytes = lib.aim_wgrad_workspace_bytes(g.shape[0], g.shape[1], a.shape[1])
+    ws = torch.empty(nbytes // 4, dtype=F32, device=g.device) if nbytes else None
+    check(lib.aim_wgrad_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(), dw.stride(0), None,
+                             g.shape[0], g.shape[1], a.shape[1], _p(ws), nbytes, _stream()), "aim_wgrad_bf16")
     if db is not None:
         colsum(g, db)        # bias gradient through the two-stage (scratch) column sum
 

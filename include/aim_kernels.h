@@ -91,7 +91,10 @@ int aim_gemm_expsum_tiles(int M, int N);
  * autograd counterpart of Adapter.D_fc1 / D_fc2 (vit_clip.py:57-58).  Nw, Kw multiples of 8.
  * ------------------------------------------------------------------------------------------ */
 int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw,
-                   float* db, int M, int Nw, int Kw, void* stream);
+                   float* db, int M, int Nw, int Kw,
+                   float* workspace /* optional: aim_wgrad_workspace_bytes(); NULL -> fp32 atomics */,
+                   int64_t workspace_bytes, void* stream);
+int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (fp32 statistics, eps inside rsqrt) -- vit_clip.py:71-77 (ln_1, ln_2, ln_pre, ln_post)
