@@ -172,8 +172,14 @@ def main():
                 dom = max(summ, key=lambda k: summ[k]["ms"])
                 d = summ[dom]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                traffic = None     # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))["kernels"]
+                    traffic = round(tj["gemm256_kernel<%d>" % dom]["hbm_bytes_per_launch"])
+                except Exception:
+                    pass
                 roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": d["launches"] / args.steps,
                         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "flops_per_launch": d["flops"] / d["launches"],
