@@ -419,8 +419,21 @@ class _BackboneFn(torch.autograd.Function):
         dev = dout.device
         frozen = model._frozen_operands()
         params = s["params"]
-        # gradient buffers (fp32, accumulated by atomics inside the kernels)
+        # Gradient buffers (fp32; every kernel ACCUMULATES into them).  With `grad_in_place` (set by
+        # dist.build_optimizer for the flat-buffer optimizer) the kernels add straight into the existing
+        # `param.grad` views of the flat gradient buffer and autograd gets None for those inputs: no
+        # temporary zero-filled tensors and no 147 small accumulate kernels per step.
         grads_out: List[Optional[torch.Tensor]] = [None] * len(params)
+        in_place = [False] * len(params)
+
+        def buf(k):
+            p_ = params[k]
+            if (model.grad_in_place and p_.requires_grad and p_.grad is not None and p_.grad.dtype == F32
+                    and p_.grad.is_contiguous() and p_.grad.device == dev):
+                in_place[k] = True
+                return p_.grad
+            return torch.zeros_like(p_, dtype=F32)
+
         layer_grads = []
         for i in range(L):
             lg = {}
@@ -428,11 +441,11 @@ class _BackboneFn(torch.autograd.Function):
                 k = 3 + (i * 3 + j) * 4
                 lg[a] = {}
                 for e, leaf in enumerate(_ADAPTER_LEAVES):
-                    g = torch.zeros_like(params[k + e], dtype=F32)
+                    g = buf(k + e)
                     lg[a][leaf] = g
                     grads_out[k + e] = g
             layer_grads.append(lg)
-        dgw, dgb = torch.zeros(D, dtype=F32, device=dev), torch.zeros(D, dtype=F32, device=dev)
+        dgw, dgb = buf(1), buf(2)
         dy = dout.permute(0, 2, 1).reshape(BT, D).contiguous().float()
         # ln_post backward touches the class rows only; every other row of the top gradient is zero
         dx = torch.zeros((M, D), dtype=F32, device=dev)
@@ -442,13 +455,13 @@ class _BackboneFn(torch.autograd.Function):
         for i in reversed(range(L)):
             dx, dxb = _block_backward(dx, dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H)
             s["ctxs"][i] = None
-        dtmp = torch.zeros((T, D), dtype=F32, device=dev)
-        ops.embed_bwd(dx, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"], dtmp,
-                      B, T, N, D)
-        grads_out[0] = dtmp.reshape(1, T, D)
+        dtmp = buf(0)
+        ops.embed_bwd(dx, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"],
+                      dtmp.view(T, D), B, T, N, D)
+        grads_out[0] = dtmp.view(1, T, D)
         grads_out[1], grads_out[2] = dgw, dgb
         for k, p_ in enumerate(params):
-            if not p_.requires_grad:
+            if not p_.requires_grad or in_place[k]:
                 grads_out[k] = None
             elif grads_out[k] is not None and grads_out[k].dtype != p_.dtype:
                 grads_out[k] = grads_out[k].to(p_.dtype)
@@ -485,6 +498,7 @@ class ViT_CLIP(nn.Module):
         self.ln_post = LayerNorm(width)
         self._frozen_cache = None
         self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
+        self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
 
     # ---- reference API ------------------------------------------------------------------------
     def init_weights(self, pretrained=None):

@@ -188,7 +188,11 @@ def build_optimizer(model: torch.nn.Module, cfg: dict):
                 break
         groups.append(g)
     if typ == "AdamW" and all(p.is_cuda for g in groups for p in g["params"]):
-        return FlatAdamW(groups, lr=cfg["lr"], betas=tuple(cfg.get("betas", (0.9, 0.999))), eps=cfg.get("eps", 1e-8),
-                         weight_decay=base_wd)
+        opt = FlatAdamW(groups, lr=cfg["lr"], betas=tuple(cfg.get("betas", (0.9, 0.999))), eps=cfg.get("eps", 1e-8),
+                        weight_decay=base_wd)
+        for m in model.modules():            # the backbone may now add its gradients straight into the flat buffer
+            if hasattr(m, "grad_in_place"):
+                m.grad_in_place = True
+        return opt
     opt_cls = getattr(torch.optim, typ)
     return opt_cls(groups, **cfg)
