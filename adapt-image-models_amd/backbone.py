@@ -123,6 +123,10 @@ class _Frozen:
         ops.cast_bf16(wfc, self.WcatT1[:, :4 * D], transpose=True)
         self.bcat1 = torch.zeros(4 * D + r, dtype=F32, device=dev)
         self.bcat1[:4 * D] = blk.mlp.c_fc.bias.detach().float()
+        # bf16 operands of the two small adapters (re-cast every step by the model's cast table)
+        self.small = {a: dict(W1=torch.empty((r, D), dtype=BF16, device=dev), W1T=torch.empty((D, r), dtype=BF16, device=dev),
+                              W2=torch.empty((D, r), dtype=BF16, device=dev), W2T=torch.empty((r, D), dtype=BF16, device=dev))
+                      for a in ("S_Adapter", "T_Adapter")}
         f = lambda p: p.detach().float().contiguous()
         self.bqkv, self.bo = f(a.in_proj_bias), f(a.out_proj.bias)
         self.bpr = f(blk.mlp.c_proj.bias)
@@ -130,24 +134,37 @@ class _Frozen:
         self.g2, self.b2 = f(blk.ln_2.weight), f(blk.ln_2.bias)
 
 
-    def stage_mlp_adapter(self, w1, b1, w2, b2):
-        """Write this step's MLP_Adapter weights into the adapter slices of the concatenated operands."""
+    def cast_entries(self, name, w1, w2):
+        """(src, dst, transpose) casts that stage one adapter's weights as bf16 operands, both orientations."""
         H4 = self.H4
-        w1f, w2f = w1.detach().float().contiguous(), w2.detach().float().contiguous()
-        ops.cast_bf16(w1f, self.Wcat1[H4:])                       # [r, D]
-        ops.cast_bf16(w2f, self.Wcat2[:, H4:])                    # [D, r]
-        ops.cast_bf16(w2f, self.WcatT2[H4:], transpose=True)      # [r, D]
-        ops.cast_bf16(w1f, self.WcatT1[:, H4:], transpose=True)   # [D, r]
-        self.bcat1[H4:] = b1.detach().float()
+        if name == "MLP_Adapter":      # adapter slices of the concatenated MLP operands
+            return [(w1, self.Wcat1[H4:], False), (w2, self.Wcat2[:, H4:], False),
+                    (w2, self.WcatT2[H4:], True), (w1, self.WcatT1[:, H4:], True)]
+        b = self.small[name]
+        return [(w1, b["W1"], False), (w1, b["W1T"], True), (w2, b["W2"], False), (w2, b["W2T"], True)]
+
+    def stage_mlp_adapter(self, w1, b1, w2, b2):
+        """Stand-alone staging of the MLP_Adapter slices (tests / callers without the model's cast table)."""
+        for src, dst, tr in self.cast_entries("MLP_Adapter", w1.detach().float().contiguous(),
+                                              w2.detach().float().contiguous()):
+            ops.cast_bf16(src, dst, transpose=tr)
+        self.stage_mlp_bias(b1, b2)
+
+    def stage_mlp_bias(self, b1, b2):
+        self.bcat1[self.H4:] = b1.detach().float()
         self.b2row = b2.detach().float().reshape(1, -1).contiguous()
 
 
 class _AdapterW:
-    """bf16 operands of one adapter for this step (weights are trainable: re-cast when they change)."""
+    """bf16 operands of one adapter for this step (weights are trainable: re-cast when they change).
+    ``bufs`` = already staged persistent operand buffers (the model's cast table filled them)."""
 
-    def __init__(self, w1, b1, w2, b2):
-        self.W1, self.W1T = _cast(w1), _cast(w1, True)     # [r, D], [D, r]
-        self.W2, self.W2T = _cast(w2), _cast(w2, True)     # [D, r], [r, D]
+    def __init__(self, w1, b1, w2, b2, bufs=None):
+        if bufs is None:
+            self.W1, self.W1T = _cast(w1), _cast(w1, True)     # [r, D], [D, r]
+            self.W2, self.W2T = _cast(w2), _cast(w2, True)     # [D, r], [r, D]
+        else:
+            self.W1, self.W1T, self.W2, self.W2T = bufs["W1"], bufs["W1T"], bufs["W2"], bufs["W2T"]
         self.b1, self.b2 = b1.detach().float().contiguous(), b2.detach().float().contiguous()
 
 
@@ -369,15 +386,17 @@ class _BackboneFn(torch.autograd.Function):
         temporal, lnp_w, lnp_b = params[0], params[1], params[2]
         need_grad = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
         frozen = model._frozen_operands()
+        model._stage_adapters(frozen, params)      # ONE launch casts all 36 adapters' weights to bf16 operands
         adp = []
         for i in range(L):
             d = {}
             for j, a in enumerate(_ADAPTERS):
                 k = 3 + (i * 3 + j) * 4
-                if a == "MLP_Adapter":      # shares the frozen MLP's GEMMs: staged into the concatenated operands
-                    frozen["blocks"][i].stage_mlp_adapter(params[k], params[k + 1], params[k + 2], params[k + 3])
+                if a == "MLP_Adapter":      # shares the frozen MLP's GEMMs (concatenated operands)
+                    frozen["blocks"][i].stage_mlp_bias(params[k + 1], params[k + 3])
                 else:
-                    d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3])
+                    d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3],
+                                     bufs=frozen["blocks"][i].small[a])
             adp.append(d)
         # patch embedding as a GEMM (conv1: kernel = stride = patch, no bias; vit_clip.py:436)
         Kp = frozen["conv"].shape[1]
@@ -499,6 +518,7 @@ class ViT_CLIP(nn.Module):
         self._frozen_cache = None
         self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
+        self._cast_table = None
 
     # ---- reference API ------------------------------------------------------------------------
     def init_weights(self, pretrained=None):
@@ -581,6 +601,33 @@ class ViT_CLIP(nn.Module):
                    blocks=[_Frozen(b) for b in self.transformer.resblocks])
         self._frozen_cache = (key, out)
         return out
+
+    def _stage_adapters(self, frozen, params):
+        """Re-cast every adapter weight (fp32 master) into its persistent bf16 operand buffers with one
+        ``aim_cast_multi`` launch.  The table of raw pointers is rebuilt only when a tensor moved."""
+        srcs = []
+        for i in range(self.layers):
+            for j, a in enumerate(_ADAPTERS):
+                k = 3 + (i * 3 + j) * 4
+                srcs += [params[k], params[k + 2]]
+        ok = all(p.dtype == F32 and p.is_contiguous() for p in srcs)
+        key = tuple(p.data_ptr() for p in srcs) + (id(frozen),)
+        if ok and (self._cast_table is None or self._cast_table[0] != key):
+            entries = []
+            for i in range(self.layers):
+                for j, a in enumerate(_ADAPTERS):
+                    k = 3 + (i * 3 + j) * 4
+                    entries += frozen["blocks"][i].cast_entries(a, params[k].detach(), params[k + 2].detach())
+            self._cast_table = (key, ops.CastTable(entries, srcs[0].device))
+        if ok:
+            self._cast_table[1].run()
+            return
+        for i in range(self.layers):           # generic path (non-fp32 / non-contiguous masters)
+            for j, a in enumerate(_ADAPTERS):
+                k = 3 + (i * 3 + j) * 4
+                for src, dst, tr in frozen["blocks"][i].cast_entries(a, params[k].detach().float().contiguous(),
+                                                                     params[k + 2].detach().float().contiguous()):
+                    ops.cast_bf16(src, dst, transpose=tr)
 
     def _trainable_list(self):
         ps = [self.temporal_embedding, self.ln_post.weight, self.ln_post.bias]

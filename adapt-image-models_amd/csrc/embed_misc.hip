@@ -333,6 +333,21 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
     if (yf) yf[i] = v;
 }
 
+// One launch for a whole table of small casts (this step's adapter weights -> bf16 GEMM operands, both
+// orientations).  grid (n descriptors, 16): block (d, y) strides over descriptor d's elements.
+__global__ __launch_bounds__(256) void cast_multi_kernel(const aim_cast_desc* __restrict__ table) {
+    const aim_cast_desc d = table[blockIdx.x];
+    const float* src = (const float*)d.src;
+    bf16_t* dst = (bf16_t*)d.dst;
+    const long long n = (long long)d.R * d.C;
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long long)gridDim.y * 256) {
+        const int r = (int)(i / d.C), c = (int)(i - (long long)r * d.C);
+        const float v = src[i];
+        if (d.transpose) dst[(long long)c * d.ldd + r] = (bf16_t)v;
+        else dst[(long long)r * d.ldd + c] = (bf16_t)v;
+    }
+}
+
 // AdamW (decoupled weight decay) on flat fp32 buffers, torch.optim.AdamW semantics.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n, float lr,
@@ -479,6 +494,13 @@ extern "C" int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int 
         hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, (bf16_t*)dst, n);
     }
     AIM_CHECK_LAUNCH("aim_cast_bf16");
+    return 0;
+}
+
+extern "C" int aim_cast_multi(const aim_cast_desc* table_dev, int n, void* stream) {
+    AIM_CHECK_ARG(table_dev && n > 0, "cast_multi: bad arguments");
+    hipLaunchKernelGGL(cast_multi_kernel, dim3(n, 16), dim3(256), 0, (hipStream_t)stream, table_dev);
+    AIM_CHECK_LAUNCH("aim_cast_multi");
     return 0;
 }
 

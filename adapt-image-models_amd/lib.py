@@ -58,6 +58,7 @@ SIGNATURES = {
     "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
     "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "aim_cast_multi": [P, I, P],
 }
 
 ABI_VERSION = 1

@@ -253,3 +253,23 @@ def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
         _chk(t_, F32, n_)
     check(load_library().aim_adamw_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
                                         beta2, eps, weight_decay, step, _stream()), "aim_adamw_flat")
+
+
+class CastTable:
+    """Device-resident table of (fp32 src -> bf16 dst [transposed]) casts, run in one launch."""
+
+    def __init__(self, entries, device):
+        import struct
+        self.keep = entries            # keep the tensors alive: the table holds raw pointers
+        raw = b"".join(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], dst.stride(0),
+                                   int(tr)) for src, dst, tr in entries)
+        for src, dst, tr in entries:
+            _chk(src, F32, "src"); _chk(dst, BF16, "dst")
+            assert src.dim() == 2 and src.is_contiguous()
+            assert tuple(dst.shape) == ((src.shape[1], src.shape[0]) if tr else tuple(src.shape))
+        self.n = len(entries)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.ptrs = tuple(src.data_ptr() for src, _, _ in entries)
+
+    def run(self):
+        check(load_library().aim_cast_multi(self.table.data_ptr(), self.n, _stream()), "aim_cast_multi")

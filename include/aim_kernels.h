@@ -175,6 +175,16 @@ int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, 
                   void* stream);
 int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
 
+/* A table of casts in ONE launch: dst = bf16(src) or bf16(src^T) with row stride ldd, for the ~150 small
+ * adapter tensors that must be re-staged as bf16 GEMM operands after every optimizer step.  The table
+ * lives in DEVICE memory (built once; the pointers are stable). */
+typedef struct aim_cast_desc {
+    const float* src;   /* [R, C] dense fp32 */
+    aim_bf16* dst;      /* [R, ldd] or, transposed, [C, ldd] */
+    int32_t R, C, ldd, transpose;
+} aim_cast_desc;
+int aim_cast_multi(const aim_cast_desc* table_dev, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer boundary: AdamW (torch.optim.AdamW semantics, decoupled decay) on ONE flat fp32 buffer
  * per parameter group -- the reference steps 149 small tensors through mmcv's optimizer hook

@@ -86,7 +86,7 @@ def test_block_against_reference_fixture(golden_dir, T):
     fz = m._frozen_operands()["blocks"][0]
     blk = m.transformer.resblocks[0]
     adp = {a: bb._AdapterW(getattr(blk, a).D_fc1.weight, getattr(blk, a).D_fc1.bias, getattr(blk, a).D_fc2.weight,
-                           getattr(blk, a).D_fc2.bias) for a in bb._ADAPTERS if a != "MLP_Adapter"}
+                           getattr(blk, a).D_fc2.bias) for a in bb._ADAPTERS if a != "MLP_Adapter"}   # stand-alone casts
     ma = blk.MLP_Adapter
     fz.stage_mlp_adapter(ma.D_fc1.weight, ma.D_fc1.bias, ma.D_fc2.weight, ma.D_fc2.bias)
     x = z["x"].permute(1, 0, 2).contiguous().reshape(B * T * N, D).to(DEV)
