@@ -304,10 +304,14 @@ def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, 
     return din
 
 
-def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T, N, H):
-    """dx2 [M, D] f32 and its bf16 copy dyb -> (dx, dx_bf16); adapter grads accumulated into ``grads``."""
-    dev = dx2.device
-    M, D = dx2.shape
+def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T, N, H):
+    """dyb = d(loss)/d(x2) [M, D] -> d(loss)/d(x); adapter grads accumulated into ``grads``.
+
+    The residual-stream GRADIENT is carried in bf16 (one tensor serves as the running residual gradient and
+    as the dgrad GEMMs' operand; LayerNorm backward adds in fp32 and rounds once per block).  The forward
+    residual stream stays fp32.  The reference's apex-O1 run keeps these gradients in fp16."""
+    dev = dyb.device
+    M, D = dyb.shape
     BT = B * T
     r, H4 = fz.r, 4 * D
     gm = grads["MLP_Adapter"]
@@ -322,15 +326,14 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
     del dcat
     # ---- ln_2
-    dx1, dx1b = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
-    ops.layernorm_bwd(dxn, c["x1"], fz.g2, c["mean2"], c["rstd2"], M, D, lddy=D, ldx=D, lddx=D, dres=dx2, dx=dx1,
-                      dx_bf16=dx1b)
+    dx1b = _empty((M, D), BF16, dev)
+    ops.layernorm_bwd(dxn, c["x1"], fz.g2, c["mean2"], c["rstd2"], M, D, lddy=D, ldx=D, lddx=D, dres=dyb, dx_bf16=dx1b)
     del dxn
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
     with _Fork(dev) as fork:
         dsv = _empty((BT, D), F32, dev)
-        ops.frame_sum(dx1, c["dms1"], dsv, BT, N, D)
+        ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
         # S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
         dsv_b = _empty((BT, D), BF16, dev)
         ops.cast_bf16(dsv, dsv_b)
@@ -350,7 +353,6 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     # ... beside the spatial attention backward on the main stream
     dao = _empty((M, D), BF16, dev)
     ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N)
-    del dx1b
     dqkv = _empty((M, 3 * D), BF16, dev)
     delta = _empty((BT, H, N), F32, dev)
     ops.attn_bwd(c["qkv"], c["ao"], dao, c["lse"], delta, dqkv, BT, N, H)
@@ -361,10 +363,9 @@ def _block_backward(dx2, dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, 
     dxl = _empty((M, D), BF16, dev)
     ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
     del dqkv
-    dx, dxb = _empty((M, D), F32, dev), _empty((M, D), BF16, dev)
-    ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1, dx=dx,
-                      dx_bf16=dxb)
-    return dx, dxb
+    dxb = _empty((M, D), BF16, dev)
+    ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
+    return dxb
 
 
 # ----------------------------------------------------------------------------------------------
@@ -467,15 +468,14 @@ class _BackboneFn(torch.autograd.Function):
         dgw, dgb = buf(1), buf(2)
         dy = dout.permute(0, 2, 1).reshape(BT, D).contiguous().float()
         # ln_post backward touches the class rows only; every other row of the top gradient is zero
-        dx = torch.zeros((M, D), dtype=F32, device=dev)
         dxb = torch.zeros((M, D), dtype=BF16, device=dev)
-        ops.layernorm_bwd(dy, s["xL"], s["gw"], s["meanp"], s["rstdp"], BT, D, lddy=D, ldx=N * D, lddx=N * D, dx=dx,
+        ops.layernorm_bwd(dy, s["xL"], s["gw"], s["meanp"], s["rstdp"], BT, D, lddy=D, ldx=N * D, lddx=N * D,
                           dx_bf16=dxb, dgamma=dgw, dbeta=dgb)
         for i in reversed(range(L)):
-            dx, dxb = _block_backward(dx, dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H)
+            dxb = _block_backward(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H)
             s["ctxs"][i] = None
         dtmp = buf(0)
-        ops.embed_bwd(dx, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"],
+        ops.embed_bwd(dxb, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"],
                       dtmp.view(T, D), B, T, N, D)
         grads_out[0] = dtmp.view(1, T, D)
         grads_out[1], grads_out[2] = dgw, dgb

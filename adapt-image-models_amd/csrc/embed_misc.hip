@@ -114,8 +114,18 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const bf16_t* __restrict_
 
 // grid (T, chunks): every wave walks rows (b, n) of frame-time t, accumulates ln_pre's input gradient
 // in registers and adds it into dtemporal[t] once at the end.
-template <int NC>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ tok,
+template <typename T>
+__device__ __forceinline__ f32x4 load4f(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *(const f32x4*)p;
+    } else {
+        const bf16x4 b = *(const bf16x4*)p;
+        return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    }
+}
+
+template <int NC, typename TDX>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const TDX* __restrict__ dx, const bf16_t* __restrict__ tok,
                                                         const float* __restrict__ cls, const float* __restrict__ pos,
                                                         const float* __restrict__ tmp, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
             const int ch = lane + c * 64;
             if (ch < nch) {
                 const f32x4 v = embed_value(tok, cls, pos, tmp, bt, n, t, N - 1, D, ch * 4);
-                const f32x4 d = *(const f32x4*)(dx + row * D + ch * 4);
+                const f32x4 d = load4f(dx + row * D + ch * 4);
                 const f32x4 gm = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -168,22 +178,23 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void frame_sum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename TX>
+__global__ __launch_bounds__(256) void frame_sum_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ out, int ntok, int D) {
     const int d4 = blockIdx.y * 256 + threadIdx.x;          // float4 column
     if (d4 * 4 >= D) return;
     const long long f = blockIdx.x;
-    const float* p = x + f * ntok * (long long)D + d4 * 4;
+    const TX* p = x + f * ntok * (long long)D + d4 * 4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     int t = 0;
     for (; t + 3 < ntok; t += 4) {
         f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (long long)(t + u) * D);
+        for (int u = 0; u < 4; ++u) v[u] = load4f(p + (long long)(t + u) * D);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc += (w ? w[t + u] : 1.0f) * v[u];
     }
-    for (; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * *(const f32x4*)(p + (long long)t * D);
+    for (; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * load4f(p + (long long)t * D);
     *(f32x4*)(out + f * D + d4 * 4) = acc;
 }
 
@@ -427,7 +438,7 @@ extern "C" int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* 
     return 0;
 }
 
-extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const float* pos,
+extern "C" int aim_embed_bwd(const void* dx, int dx_is_bf16, const aim_bf16* tok, const float* cls, const float* pos,
                              const float* temporal, const float* gamma, const float* mean, const float* rstd,
                              float* dtemporal, int B, int T, int N, int D, void* stream) {
     AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_bwd: bad shape N=%d D=%d", N, D);
@@ -435,9 +446,13 @@ extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* 
     int chunks = (B * N + 3) / 4;
     const int want = (2048 + T - 1) / T;
     if (chunks > want) chunks = want;
-#define AIM_EB(NC)                                                                                                 \
-    hipLaunchKernelGGL(embed_bwd_kernel<NC>, dim3(T, chunks), dim3(256), 0, (hipStream_t)stream, dx, (const bf16_t*)tok, \
-                       cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D)
+#define AIM_EB(NC)                                                                                                     \
+    if (dx_is_bf16)                                                                                                    \
+        hipLaunchKernelGGL((embed_bwd_kernel<NC, bf16_t>), dim3(T, chunks), dim3(256), 0, (hipStream_t)stream,          \
+                           (const bf16_t*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D); \
+    else                                                                                                               \
+        hipLaunchKernelGGL((embed_bwd_kernel<NC, float>), dim3(T, chunks), dim3(256), 0, (hipStream_t)stream,           \
+                           (const float*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D)
     const int nc = (D + 255) / 256;
     if (nc <= 1) AIM_EB(1); else if (nc == 2) AIM_EB(2); else if (nc == 3) AIM_EB(3); else if (nc == 4) AIM_EB(4); else AIM_EB(8);
 #undef AIM_EB
@@ -445,9 +460,14 @@ extern "C" int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* 
     return 0;
 }
 
-extern "C" int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream) {
+extern "C" int aim_frame_sum(const void* x, int x_is_bf16, const float* w, float* out, int frames, int ntok, int D, void* stream) {
     AIM_CHECK_ARG(frames > 0 && ntok > 0 && D > 0 && (D % 4) == 0 && x && out, "frame_sum: bad arguments");
-    hipLaunchKernelGGL(frame_sum_kernel, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, out, ntok, D);
+    if (x_is_bf16)
+        hipLaunchKernelGGL(frame_sum_kernel<bf16_t>, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, w, out, ntok, D);
+    else
+        hipLaunchKernelGGL(frame_sum_kernel<float>, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, w, out, ntok, D);
     AIM_CHECK_LAUNCH("aim_frame_sum");
     return 0;
 }

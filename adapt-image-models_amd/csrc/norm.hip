@@ -67,11 +67,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
-template <int NC, typename TDY>
+template <int NC, typename TDY, typename TDR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     const float* __restrict__ rstd, const TDR* __restrict__ dres,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dxb, long long lddx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows, int D) {
@@ -120,8 +120,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs * (g[c][e] - m1 - xh[c][e] * m2);
             if (dres) {
-                const f32x4 r = *(const f32x4*)(dres + (long long)row * lddx + ch * 4);
-                o += r;
+                if constexpr (sizeof(TDR) == 4) {
+                    o += *(const f32x4*)(dres + (long long)row * lddx + ch * 4);
+                } else {
+                    const bf16x4 rb = *(const bf16x4*)(dres + (long long)row * lddx + ch * 4);
+                    o += f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+                }
             }
             if (dx) *(f32x4*)(dx + (long long)row * lddx + ch * 4) = o;
             if (dxb) *(bf16x4*)(dxb + (long long)row * lddx + ch * 4) = pack4(o[0], o[1], o[2], o[3]);
@@ -149,26 +153,27 @@ extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
 }
 
 extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                                 const float* mean, const float* rstd, const float* dres, float* dx,
+                                 const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,
                                  aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int rows, int D,
                                  void* stream) {
     AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_bwd: bad shape rows=%d D=%d", rows, D);
     AIM_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "layernorm_bwd: null pointer");
     AIM_CHECK_ARG((!dgamma) == (!dbeta), "layernorm_bwd: dgamma and dbeta go together");
     AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
+#define AIM_LN_BWD_T(NC, TDY, TDR)                                                                                  \
+    hipLaunchKernelGGL((ln_bwd_kernel<NC, TDY, TDR>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,        \
+                       (const TDY*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, (const TDR*)dres, dx,   \
+                       (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta, rows, D)
 #define AIM_LN_BWD(NC)                                                                                              \
-    if (dy_is_bf16)                                                                                                 \
-        hipLaunchKernelGGL((ln_bwd_kernel<NC, bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,     \
-                           (const bf16_t*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, dres, dx,        \
-                           (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta, rows, D);                                \
-    else                                                                                                            \
-        hipLaunchKernelGGL((ln_bwd_kernel<NC, float>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,       \
-                           (const float*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, dres, dx,          \
-                           (bf16_t*)dx_bf16, (long long)lddx, dgamma, dbeta, rows, D)
+    if (dy_is_bf16 && dres_is_bf16) AIM_LN_BWD_T(NC, bf16_t, bf16_t);                                               \
+    else if (dy_is_bf16) AIM_LN_BWD_T(NC, bf16_t, float);                                                           \
+    else if (dres_is_bf16) AIM_LN_BWD_T(NC, float, bf16_t);                                                         \
+    else AIM_LN_BWD_T(NC, float, float)
     const int nc = (D + 255) / 256;
     if (nc <= 1) AIM_LN_BWD(1); else if (nc == 2) AIM_LN_BWD(2); else if (nc == 3) AIM_LN_BWD(3);
     else if (nc == 4) AIM_LN_BWD(4); else AIM_LN_BWD(8);
 #undef AIM_LN_BWD
+#undef AIM_LN_BWD_T
     AIM_CHECK_LAUNCH("aim_layernorm_bwd");
     return 0;
 }

@@ -44,7 +44,7 @@ SIGNATURES = {
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
-    "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, P, P, L, P, P, I, I, P],
+    "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, I, P, P, L, P, P, I, I, P],
     "aim_attn_fwd": [P, P, P, I, I, I, P],
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
@@ -52,8 +52,8 @@ SIGNATURES = {
     "aim_lambda": [P, P, I, P, I, P, P, I, I, I, F, P],
     "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],
     "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
-    "aim_embed_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
-    "aim_frame_sum": [P, P, P, I, I, I, P],
+    "aim_embed_bwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "aim_frame_sum": [P, I, P, P, I, I, I, P],
     "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P, L, P],
     "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],

@@ -141,13 +141,16 @@ def layernorm_fwd(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, ldy=
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=None, dx=None, dx_bf16=None,
                   dgamma=None, dbeta=None):
-    for n_, t_ in (("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dres", dres),
+    for n_, t_ in (("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd),
                    ("dx", dx), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t_, F32, n_)
     _chk(dx_bf16, BF16, "dx_bf16")
     _chk(dy, dy.dtype if dy.dtype in (F32, BF16) else F32, "dy")
+    if dres is not None:
+        _chk(dres, dres.dtype if dres.dtype in (F32, BF16) else F32, "dres")
     check(load_library().aim_layernorm_bwd(dy.data_ptr(), int(dy.dtype == BF16), lddy, x.data_ptr(), ldx, gamma.data_ptr(),
-                                           mean.data_ptr(), rstd.data_ptr(), _p(dres), _p(dx), _p(dx_bf16), lddx,
+                                           mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                                           int(dres is not None and dres.dtype == BF16), _p(dx), _p(dx_bf16), lddx,
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
 
 
@@ -208,17 +211,18 @@ def embed_ln(tok, cls, pos, temporal, gamma, beta, x, mean, rstd, B, T, N, D, ep
 
 def embed_bwd(dx, tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D):
     _chk(tok, BF16, "tok")
-    for n_, t_ in (("dx", dx), ("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("mean", mean),
+    for n_, t_ in (("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("mean", mean),
                    ("rstd", rstd), ("dtemporal", dtemporal)):
         _chk(t_, F32, n_)
-    check(load_library().aim_embed_bwd(dx.data_ptr(), tok.data_ptr(), cls.data_ptr(), pos.data_ptr(),
+    _chk(dx, dx.dtype if dx.dtype in (F32, BF16) else F32, "dx")
+    check(load_library().aim_embed_bwd(dx.data_ptr(), int(dx.dtype == BF16), tok.data_ptr(), cls.data_ptr(), pos.data_ptr(),
                                        temporal.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        dtemporal.data_ptr(), B, T, N, D, _stream()), "aim_embed_bwd")
 
 
 def frame_sum(x, w, out, frames, ntok, D):
-    _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(out, F32, "out")
-    check(load_library().aim_frame_sum(x.data_ptr(), _p(w), out.data_ptr(), frames, ntok, D, _stream()),
+    _chk(x, x.dtype if x.dtype in (F32, BF16) else F32, "x"); _chk(w, F32, "w"); _chk(out, F32, "out")
+    check(load_library().aim_frame_sum(x.data_ptr(), int(x.dtype == BF16), _p(w), out.data_ptr(), frames, ntok, D, _stream()),
           "aim_frame_sum")
 
 

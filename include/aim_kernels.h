@@ -107,7 +107,7 @@ int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
                       int rows, int D, float eps, void* stream);
 int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0) */, int64_t lddy,
                       const float* x, int64_t ldx, const float* gamma,
-                      const float* mean, const float* rstd, const float* dres, float* dx,
+                      const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,
                       aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta,
                       int rows, int D, void* stream);
 
@@ -156,7 +156,7 @@ int aim_patchify(const void* imgs, int in_dtype /* 0 f32, 1 uint8, 2 bf16 */, co
 int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* pos, const float* temporal,
                  const float* gamma, const float* beta, float* x, float* mean, float* rstd,
                  int B, int T, int N, int D, float eps, void* stream);
-int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const float* pos,
+int aim_embed_bwd(const void* dx, int dx_is_bf16, const aim_bf16* tok, const float* cls, const float* pos,
                   const float* temporal, const float* gamma, const float* mean, const float* rstd,
                   float* dtemporal, int B, int T, int N, int D, void* stream);
 
@@ -167,7 +167,7 @@ int aim_embed_bwd(const float* dx, const aim_bf16* tok, const float* cls, const 
  *   cast      : f32 -> bf16 (optionally transposed [R,C] -> [C,R]) for weight staging
  *   scale_rows: y[r][c] = s[r] * x[r][c]  (f32 x -> bf16 y), used for lamda * crs_attn
  * ------------------------------------------------------------------------------------------ */
-int aim_frame_sum(const float* x, const float* w, float* out, int frames, int ntok, int D, void* stream);
+int aim_frame_sum(const void* x, int x_is_bf16, const float* w, float* out, int frames, int ntok, int D, void* stream);
 int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at, int ntok,
                     float* out, int M, int C, float* workspace /* optional: >= 1024*C floats -> two-stage, no atomics */,
                     int64_t workspace_bytes, void* stream);

@@ -107,7 +107,7 @@ def test_block_against_reference_fixture(golden_dir, T):
     grads = {a: {leaf: torch.zeros_like(_param(a, leaf), dtype=torch.float32) for leaf in bb._ADAPTER_LEAVES}
              for a in bb._ADAPTERS}
     g = z["g"].permute(1, 0, 2).contiguous().reshape(B * T * N, D).to(DEV)
-    dx, _ = bb._block_backward(g, g.to(torch.bfloat16), c, fz, adp, grads, B, T, N, H)
+    dx = bb._block_backward(g.to(torch.bfloat16), c, fz, adp, grads, B, T, N, H)
     dx_ref = z["dx"].permute(1, 0, 2).reshape(B * T * N, D)
     assert _relerr(dx, dx_ref) < 3e-2, _relerr(dx, dx_ref)
     for a in bb._ADAPTERS:
