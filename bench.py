@@ -163,8 +163,9 @@ def main():
         }
         roof = None
         if timing:
-            names = {0: "gemm_kernel<EPI_BF16>", 1: "gemm_kernel<EPI_ACT>", 2: "gemm_kernel<EPI_DACT>",
-                     3: "gemm_kernel<EPI_F32>", 4: "gemm_kernel<EPI_EXPSUM>"}
+            # launches of >= 10 GFLOP: the persistent 256x256 kernel (gemm256.hip) except the batched EXPSUM (gemm.hip)
+            names = {0: "gemm256_kernel<EPI_BF16>", 1: "gemm256_kernel<EPI_ACT>", 2: "gemm256_kernel<EPI_DACT>",
+                     3: "gemm256_kernel<EPI_F32>", 4: "gemm_kernel<EPI_EXPSUM>"}
             summ = ops.GEMM_TIMER.summary()
             if summ:
                 tot_ms = sum(d["ms"] for d in summ.values())
