@@ -3,6 +3,7 @@
 #pragma once
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
+#include <type_traits>
 
 struct RowFactors {
     float rs, vs;
@@ -132,23 +133,52 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue of one wave's 128x64 accumulator tile (acc[8][4], 16x16 MFMA fragments), re-tiled through a
-// private LDS scratch (16 rows x 272 B) so global accesses are whole 128-256 B row segments.
-// Memory-side inputs are software-pipelined: the loads of row-block p+1 are issued BEFORE the stores
-// of row-block p, so a wave never waits on a store acknowledgement (vmcnt is in-order and counts
-// stores) and keeps two row-blocks of loads in flight.  Column-only inputs (bias) are loaded once.
+// private LDS scratch (8 rows x 272 B) so global accesses are whole 128-256 B row segments.
+//
+// EVERY global access here is a buffer instruction: lanes past N carry an out-of-range offset and rows
+// past M fall off the end of the resource (loads return 0, stores are dropped), so there is no
+// exec-masked branch around any VMEM instruction.  That matters because vmcnt is in-order and counts
+// stores -- with a load under a divergent branch the compiler can only merge control flow with
+// `s_waitcnt vmcnt(0)`, which makes each 8-row sub-pass wait for the previous sub-pass's store
+// acknowledgement and for the next tile's staged operand loads (measured: ~11 us of a ~31 us tile).
+// Per-row factors (af/at/bt) are computed once per tile into a wave-private LDS table, so the
+// sub-passes themselves contain no load besides the prefetched resid / aux rows.
+// Null optional inputs (bias, resid, vec, af, at, bt) get a zero-length resource and read as 0.
 // ------------------------------------------------------------------------------------------------
 constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad
-constexpr int EPI_SCRATCH = 8 * EPI_RS;          // bytes per wave: 8 rows at a time (fits beside the K-loop images)
+constexpr int EPI_ROWFAC = 8 * EPI_RS;           // offset of the per-row factor table: 128 rows x {rs, vs}
+constexpr int EPI_SCRATCH = 8 * EPI_RS + 128 * 8;   // bytes per wave (fits beside the K-loop images)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// resource over `rows` rows of `ld_bytes` starting at base + byte_off; null base or rows <= 0 -> empty
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, long long byte_off, long long bytes) {
+    const unsigned n = (!base || bytes <= 0) ? 0u : (bytes > 0x7fffffffLL ? 0x7fffffffu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)base + byte_off), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ bf16x8 buf_load_h8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+template <typename V>
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, V v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+// a running byte offset the compiler may not pre-compute for all 16 sub-passes (that costs 16 VGPRs and spills)
+__device__ __forceinline__ void epi_advance(unsigned& voff, unsigned step) {
+    voff += step;
+    asm volatile("" : "+v"(voff));
+}
 
 template <int EPI>
-struct RowIn {       // memory-side inputs of one (row, lane) 4-column fragment
-    f32x4 resid;
-    bf16x4 aux;
-};
-
-template <int EPI>
-__device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base,
-                                              int n_base, int lane) {
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base_in,
+                                              int n_base_in, int lane) {
+    const int m_base = __builtin_amdgcn_readfirstlane(m_base_in), n_base = __builtin_amdgcn_readfirstlane(n_base_in);
     const int frow = lane & 15, fq = lane >> 4;
     // half of one 16-row MFMA tile -> scratch rows 0..7 (the lanes holding the other half sit out)
     auto dump8 = [&](int mt, int half) {
@@ -161,52 +191,69 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // writes landed before other lanes read them
     };
     const bool rowf = g.af || g.at || g.vec;
+    const int rows_left = min(g.M - m_base, 128), cols_left = g.N - n_base;   // may be <= 0: every lane out of range
+    const __amdgpu_buffer_rsrc_t rBias = epi_rsrc(g.bias, (long long)n_base * 4, 0x7fffffff);
+    AIM_LDS float* rowfac = (AIM_LDS float*)(scr + EPI_ROWFAC);
+    if (rowf) {
+        // rows lane and lane + 64 of the wave tile: rs = af[frame] * at[tok], vs = bt[tok] (neutral when null)
+        const __amdgpu_buffer_rsrc_t rAf = epi_rsrc(g.af, 0, 0x7fffffff), rAt = epi_rsrc(g.at, 0, 0x7fffffff),
+                                     rBt = epi_rsrc(g.bt, 0, 0x7fffffff);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m_base + h * 64 + lane;
+            const int mc = m < g.M ? m : g.M - 1;
+            const int frame = mc / g.ntok, tok = mc - frame * g.ntok;
+            const float a = buf_load_f1(rAf, (unsigned)frame * 4u), t = buf_load_f1(rAt, (unsigned)tok * 4u),
+                        b = buf_load_f1(rBt, (unsigned)tok * 4u);
+            f32x2 f;
+            f[0] = (g.af ? a : 1.0f) * (g.at ? t : 1.0f);
+            f[1] = g.vec ? (g.bt ? b : 1.0f) : 0.0f;
+            *(AIM_LDS f32x2*)(rowfac + (h * 64 + lane) * 2) = f;
+        }
+    }
+
     if constexpr (EPI != EPI_F32) {
         // bf16 outputs (BF16 / ACT / DACT): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
         // global access is a 16-byte-per-lane, whole-128-B-row-segment instruction (the 8-byte form is
-        // store-issue-bound).  DACT's saved pre-activations are prefetched one 32-row group ahead.
+        // store-issue-bound).  N and the leading dimensions are multiples of 8 here (checked by the launcher).
+        // DACT's saved pre-activations are prefetched one 32-row group ahead.
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const bool ncol = c8 < cols_left;
         const int n = n_base + c8;
-        const bool ncol = n < g.N;
-        const bool wide = (g.ldo % 8) == 0 && n + 8 <= g.N && (EPI != EPI_ACT || (g.ldo2 % 8) == 0) &&
-                          (EPI != EPI_DACT || (g.ldaux % 8) == 0);
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (g.bias && ncol) {
-            b0 = *(const f32x4*)(g.bias + n);
-            if (n + 4 < g.N) b1 = *(const f32x4*)(g.bias + n + 4);
-        }
+        const __amdgpu_buffer_rsrc_t rOut =
+            epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 2, (long long)rows_left * g.ldo * 2);
+        const __amdgpu_buffer_rsrc_t rOut2 = epi_rsrc(EPI == EPI_ACT ? g.out2 : nullptr,
+                                                      ((long long)m_base * g.ldo2 + n_base) * 2, (long long)rows_left * g.ldo2 * 2);
+        const __amdgpu_buffer_rsrc_t rAux = epi_rsrc(EPI == EPI_DACT ? g.aux : nullptr,
+                                                     ((long long)m_base * g.ldaux + n_base) * 2, (long long)rows_left * g.ldaux * 2);
+        const f32x4 b0 = buf_load_f4(rBias, ncol ? (unsigned)c8 * 4u : AIM_OOB);
+        const f32x4 b1 = buf_load_f4(rBias, ncol ? (unsigned)c8 * 4u + 16u : AIM_OOB);
         const int act = col_act(g, n);
         const bool rs_on = EPI == EPI_BF16 || g.n_split == 0 || n >= g.n_split;
-        auto load_aux = [&](int grp, bf16x8 (&ax)[4]) {
+        unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * 2u : AIM_OOB;
+        unsigned voO2 = ncol ? (unsigned)(r8 * g.ldo2 + c8) * 2u : AIM_OOB;
+        unsigned voA = ncol ? (unsigned)(r8 * g.ldaux + c8) * 2u : AIM_OOB;
+        const unsigned stO = (unsigned)g.ldo * 16u, stO2 = (unsigned)g.ldo2 * 16u, stA = (unsigned)g.ldaux * 16u;
+        auto load_aux = [&](bf16x8 (&ax)[4]) {
             if constexpr (EPI == EPI_DACT) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int m = m_base + grp * 32 + t * 8 + r8;
-                    if (m < g.M && ncol) {
-                        const bf16_t* ap = (const bf16_t*)g.aux + (long long)m * g.ldaux + n;
-                        if (wide) {
-                            ax[t] = *(const bf16x8*)ap;
-                        } else {
-                            const bf16x4 lo = *(const bf16x4*)ap;
-                            bf16x4 hi = lo;
-                            if (n + 4 < g.N) hi = *(const bf16x4*)(ap + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { ax[t][e] = lo[e]; ax[t][4 + e] = hi[e]; }
-                        }
-                    }
+                    ax[t] = buf_load_h8(rAux, voA);
+                    epi_advance(voA, stA);
                 }
             }
         };
-        auto finish8 = [&](int grp, const bf16x8 (&ax)[4]) {
+        auto finish8 = [&](int grp, const bf16x8 (&ax)[4], auto ROWF) {
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) {
                 dump8(grp * 2 + (sp >> 1), sp & 1);
                 const f32x4 v0 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4);
                 const f32x4 v1 = *(const AIM_LDS f32x4*)(scr + r8 * EPI_RS + c8 * 4 + 16);
-                const int m = m_base + grp * 32 + sp * 8 + r8;
-                if (m >= g.M || !ncol) continue;
                 float rs = 1.0f;
-                if (rowf && rs_on) rs = row_factors(g, m).rs;
+                if constexpr (decltype(ROWF)::value) {
+                    const float f = rowfac[(grp * 32 + sp * 8 + r8) * 2];
+                    rs = rs_on ? f : 1.0f;
+                }
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
@@ -228,55 +275,57 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                         o[e] = (bf16_t)(rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x)));
                     }
                 }
-                bf16_t* op = (bf16_t*)g.out + (long long)m * g.ldo + n;
-                if (wide) {
-                    *(bf16x8*)op = o;
-                    if constexpr (EPI == EPI_ACT) *(bf16x8*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
-                } else {       // ragged N / odd strides: two 4-column halves
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        if (n + 4 * hh >= g.N) break;
-                        *(bf16x4*)(op + 4 * hh) = bf16x4{o[4 * hh], o[4 * hh + 1], o[4 * hh + 2], o[4 * hh + 3]};
-                        if constexpr (EPI == EPI_ACT)
-                            *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n + 4 * hh) =
-                                bf16x4{pre[4 * hh], pre[4 * hh + 1], pre[4 * hh + 2], pre[4 * hh + 3]};
-                    }
+                buf_store16(rOut, voO, o);
+                epi_advance(voO, stO);
+                if constexpr (EPI == EPI_ACT) {
+                    buf_store16(rOut2, voO2, pre);
+                    epi_advance(voO2, stO2);
                 }
             }
         };
         bf16x8 xa[4], xb[4];
-        load_aux(0, xa);
-        load_aux(1, xb); finish8(0, xa);
-        load_aux(2, xa); finish8(1, xb);
-        load_aux(3, xb); finish8(2, xa);
-        finish8(3, xb);
+        auto run8 = [&](auto ROWF) {
+            load_aux(xa);
+            load_aux(xb); finish8(0, xa, ROWF);
+            load_aux(xa); finish8(1, xb, ROWF);
+            load_aux(xb); finish8(2, xa, ROWF);
+            finish8(3, xb, ROWF);
+        };
+        if (rowf) run8(std::true_type{}); else run8(std::false_type{});
     } else {
+        // fp32 output (residual stream): 16 lanes x 4 columns per row, 4 rows per wave-instruction
         const int rr = lane >> 4, cc = (lane & 15) * 4;
-        const int n = n_base + cc;
-        const bool ncol = n < g.N;
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (g.bias && ncol) bias4 = *(const f32x4*)(g.bias + n);
-        const int act = col_act(g, n);
-        const bool rs_on = !(EPI == EPI_ACT || EPI == EPI_DACT) || g.n_split == 0 || n >= g.n_split;
-        constexpr bool HAS_IN = (EPI == EPI_F32 || EPI == EPI_DACT);
+        const bool ncol = cc < cols_left;
+        const __amdgpu_buffer_rsrc_t rOut =
+            epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 4, (long long)rows_left * g.ldo * 4);
+        const __amdgpu_buffer_rsrc_t rRes =
+            epi_rsrc(g.resid, ((long long)m_base * g.ldr + n_base) * 4, (long long)rows_left * g.ldr * 4);
+        const f32x4 bias4 = buf_load_f4(rBias, ncol ? (unsigned)cc * 4u : AIM_OOB);
+        // `vec` rows are per frame, and the wave tile's 128 rows touch at most two frames (ntok >= 128, checked
+        // by the launcher): both candidate rows are fetched once and selected per row
+        f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        int bnd = 1 << 30;            // first tile-local row that belongs to the second frame
+        if (g.vec) {
+            const int mcl = m_base < g.M ? m_base : g.M - 1;
+            const int frame0 = mcl / g.ntok;
+            const int nframes = (g.M + g.ntok - 1) / g.ntok;
+            bnd = (frame0 + 1) * g.ntok - m_base;
+            const __amdgpu_buffer_rsrc_t rVec = epi_rsrc(g.vec, (long long)n_base * 4, 0x7fffffff);
+            w0 = buf_load_f4(rVec, ncol ? (unsigned)(frame0 * g.ldv + cc) * 4u : AIM_OOB);
+            w1 = buf_load_f4(rVec, (ncol && frame0 + 1 < nframes) ? (unsigned)((frame0 + 1) * g.ldv + cc) * 4u : AIM_OOB);
+        }
+        unsigned voO = ncol ? (unsigned)(rr * g.ldo + cc) * 4u : AIM_OOB;
+        unsigned voR = ncol ? (unsigned)(rr * g.ldr + cc) * 4u : AIM_OOB;
+        const unsigned stO = (unsigned)g.ldo * 16u, stR = (unsigned)g.ldr * 16u;     // 4 rows of fp32
         // group = 32 rows (two MFMA row-tiles): 8 rows per lane, rows t*4 + rr of the group
-        auto load_rows = [&](int grp, RowIn<EPI> (&ri)[8]) {
-            if constexpr (HAS_IN) {
+        auto load_rows = [&](f32x4 (&ri)[8]) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int m = m_base + grp * 32 + t * 4 + rr;
-                    ri[t].resid = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (m < g.M && ncol) {
-                        if constexpr (EPI == EPI_F32) {
-                            if (g.resid) ri[t].resid = *(const f32x4*)(g.resid + (long long)m * g.ldr + n);
-                        }
-                        if constexpr (EPI == EPI_DACT)
-                            ri[t].aux = *(const bf16x4*)((const bf16_t*)g.aux + (long long)m * g.ldaux + n);
-                    }
-                }
+            for (int t = 0; t < 8; ++t) {
+                ri[t] = buf_load_f4(rRes, voR);
+                epi_advance(voR, stR);
             }
         };
-        auto finish = [&](int grp, const RowIn<EPI> (&ri)[8]) {
+        auto finish = [&](int grp, const f32x4 (&ri)[8], auto ROWF) {
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) {      // sub-pass: group rows 8*sp .. 8*sp+7
                 dump8(grp * 2 + (sp >> 1), sp & 1);
@@ -284,45 +333,30 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 for (int tt = 0; tt < 2; ++tt) {
                     const int t = sp * 2 + tt;
                     f32x4 v = *(const AIM_LDS f32x4*)(scr + (tt * 4 + rr) * EPI_RS + cc * 4);
-                    const int m = m_base + grp * 32 + t * 4 + rr;
-                    if (m >= g.M || !ncol) continue;
-                    RowFactors rf{1.0f, 0.0f, 0};
-                    if (rowf && rs_on) rf = row_factors(g, m);
-                    const float rs = rf.rs;
-                    if (EPI == EPI_F32 && g.rs_bias_only) v += rs * bias4; else v += bias4;
-                    if constexpr (EPI == EPI_ACT) {
-                        const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
-                        *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
-                        float a[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = (float)pre[e];
-                            a[e] = rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x));
-                        }
-                        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
-                    } else if constexpr (EPI == EPI_DACT) {
-                        float a[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = (float)ri[t].aux[e];
-                            a[e] = rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x));
-                        }
-                        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(a[0], a[1], a[2], a[3]);
-                    } else {   // EPI_F32
-                        if (!g.rs_bias_only) v *= rs;
-                        if (g.vec) v += rf.vs * *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
-                        v += ri[t].resid;
-                        *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;
+                    if constexpr (decltype(ROWF)::value) {
+                        const int r0 = grp * 32 + t * 4;           // uniform part of the tile-local row r0 + rr
+                        const f32x2 f = *(const AIM_LDS f32x2*)(rowfac + rr * 2 + r0 * 2);
+                        // rs_bias_only: v + rs*b, else (v + b)*rs -- one form, no branch
+                        v = v * (g.rs_bias_only ? 1.0f : f[0]) + f[0] * bias4;
+                        v += f[1] * (rr >= bnd - r0 ? w1 : w0);
+                    } else {
+                        v += bias4;
                     }
+                    v += ri[t];
+                    buf_store16(rOut, voO, v);
+                    epi_advance(voO, stO);
                 }
             }
         };
         // loads of group p+1 are issued before the stores of group p: a wave never waits on a store ack
-        RowIn<EPI> ra[8], rb[8];
-        load_rows(0, ra);
-        load_rows(1, rb); finish(0, ra);
-        load_rows(2, ra); finish(1, rb);
-        load_rows(3, rb); finish(2, ra);
-        finish(3, rb);
+        f32x4 ra[8], rb[8];
+        auto run4 = [&](auto ROWF) {
+            load_rows(ra);
+            load_rows(rb); finish(0, ra, ROWF);
+            load_rows(ra); finish(1, rb, ROWF);
+            load_rows(rb); finish(2, ra, ROWF);
+            finish(3, rb, ROWF);
+        };
+        if (rowf) run4(std::true_type{}); else run4(std::false_type{});
     }
 }
