@@ -7,18 +7,18 @@
 // (128 accumulator VGPRs).  LDS = 2 K-tile buffers x {A_lo, A_hi, B_lo, B_hi} half-tiles of
 // 128 rows x 64 k (16 KiB each, XOR-swizzled image of aim_common.h) = 128 KiB, one block per CU.
 //
-// Schedule: one loop iteration = 2 K-tiles (E = even buffer, O = odd buffer) = 8 phases.  Each phase
-//   { optional fragment ds_reads ; stage ONE half-tile (2 buffer_load...lds per wave) ;
-//     [phases 4, 8: s_waitcnt vmcnt(6)] ; s_barrier ; s_waitcnt lgkmcnt(0) ; 16 MFMA ; s_barrier }.
-// A wave reads all its B fragments and the first 64-row A sub-block in phase 1 (5), the second A
-// sub-block in phase 3 (7), so a buffer's B halves are free after phase 1 (5) and its A halves after
-// phase 3 (7).  Staging order  ph1 O.A_hi(t+1) | ph2 E.B_lo(t+2) | ph3 E.B_hi | ph4 E.A_lo | ph5 E.A_hi |
-// ph6 O.B_lo(t+3) | ph7 O.B_hi | ph8 O.A_lo  keeps three half-tiles (6 loads per wave) in flight across
-// every wait: vmcnt(6) at phase 4 retires tile t+1 (read from phase 5 on), at phase 8 tile t+2 (read
-// from the next phase 1 on).  RAW: every read of a staged half-tile is at least one barrier after the
-// counted wait that retired it.  WAR: a half-tile is re-staged one phase after its last ds_read, whose
-// lgkmcnt(0) precedes that phase's closing barrier.  Tiles past K are staged with out-of-range
-// offsets (zero fill, still counted by vmcnt) so the counts are uniform.
+// Schedule: one loop iteration = 2 K-tiles (even -> buffer 0, odd -> buffer 1) = 4 phases.  Each phase
+//   { fragment ds_reads ; stage TWO half-tiles (4 buffer_load...lds per wave) ; [s_waitcnt vmcnt(4)] ;
+//     s_waitcnt lgkmcnt(0) ; s_barrier ; 32 MFMA ; s_barrier }.
+// The two wave groups (wm = 0 | 1: one wave of each on every SIMD) run ONE BARRIER apart, so while one
+// group issues its 32 MFMAs the other reads fragments and issues LDS-DMA: the matrix pipe, the LDS and
+// the vector-memory issue work together instead of in turns.  (Measured per K-step at K=3072, shader
+// cycles: 8 lock-step phases 4000, 8 skewed phases 3300, 4 skewed phases 2700; MFMA floor 2048.  An
+// LDS-DMA piece costs the issuing wave ~100 cycles, so the read phase must not be longer than 32 MFMAs.)
+// A wave reads all its B fragments and the first 64-row A sub-block in phase a (c), the second A
+// sub-block in phase b (d); staging order and the RAW / WAR argument are spelled out at the loop.
+// Tiles past K are staged with out-of-range offsets (zero fill, still counted by vmcnt) so the counts
+// are uniform.  The skew is given back before each tile's epilogue so both groups' epilogues overlap.
 //
 // The kernel is PERSISTENT (one workgroup per CU walks the tiles): the look-ahead of the staging schedule runs
 // across tile boundaries, so only the very first tile of a workgroup pays a prologue, and the epilogue
@@ -79,7 +79,8 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
 // the schedule's look-ahead (up to 3 K-tiles) simply runs into the NEXT tile's first K-tiles, so its
 // prologue latency is hidden behind this tile's last MFMAs and its epilogue.
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int ngroups) {
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int ngroups, int phase_skew,
+                                                      unsigned long long* probe, int probe_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
     AIM_LDS char* escr = smem + 2 * BUF;          // epilogue scratch lives beside the K-loop images
@@ -119,6 +120,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 
     // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
     auto stage = [&](int buf, int which, int slot) {
+#ifdef AIM_X_NOSTAGE
+        return;
+#endif
         const bool in_next = slot >= nkp;
         const int kt = in_next ? slot - nkp : slot;
         const int k0 = kt * 64;
@@ -140,9 +144,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     };
 
     f32x4 acc[8][4];
-    bf16x8 af[4][2], bfr[4][2];
+    bf16x8 af[4][2] = {}, bfr[4][2] = {};
 
     auto read_b = [&](int buf) {
+#ifdef AIM_X_NOLDS
+        return;
+#endif
         const AIM_LDS char* sB = smem + buf * BUF + OFF_B + (wn >> 1) * HT;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -150,6 +157,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
             for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = lds_read8(sB + swz_off((wn & 1) * 64 + j * 16 + frow, ks * 4 + fq));
     };
     auto read_a = [&](int buf, int sub) {
+#ifdef AIM_X_NOLDS
+        return;
+#endif
         const AIM_LDS char* sA = smem + buf * BUF + OFF_A + wm * HT;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -158,6 +168,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     };
     // 16 MFMA: A sub-block `sub` (4 m-tiles) x B tiles {jb, jb+1} x 2 k-substeps
     auto mma = [&](int sub, int jb) {
+#ifdef AIM_X_NOMFMA
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bfr[jb + j][ks]));
+        }
+        return;
+#endif
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -171,72 +191,113 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     };
 #define AIM_BAR() __builtin_amdgcn_s_barrier()
 #define AIM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define AIM_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define AIM_VM4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 
     // prologue (first tile only): K-tile 0 complete, three half-tiles of K-tile 1 in flight
     stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);
-    stage(1, 2, 1); stage(1, 3, 1); stage(1, 0, 1);
-    AIM_VM6();
+    stage(1, 2, 1); stage(1, 3, 1);
+    AIM_VM4();
     AIM_BAR();
+    // The two wave groups (wm = 0 | 1; one wave of each per SIMD) run ONE BARRIER apart: while one group issues its
+    // phase's MFMAs the other reads its fragments / issues its stages, so the matrix pipe and the LDS are busy
+    // together instead of in turns.  RAW is safe because a buffer is read a full phase after the counted vmcnt +
+    // barrier that retires it; WAR because B (read by both groups) is waited for before the reading phase's barrier
+    // and A halves are private to one group.
+    // The skew is taken at the top of every tile and given back before its epilogue, so both groups' epilogues
+    // run together (skewed epilogues serialise: the leading group would wait at its next barrier for the other's).
 
+#ifdef AIM_X_STAMPS      // diagnostic build only (tools/probe_gemm.py STAMPS=1): shader-clock stamps of one iteration
+    unsigned long long stamps[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) stamps[i] = 0;
+    int stamp_arm = 0;
+#define AIM_STAMP(i) do { if (stamp_arm) { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define AIM_STAMP(i)
+#endif
+    int probe_i = 0;
     for (; seq < nseq; seq += wg_per_group) {
+        unsigned long long tp0 = 0, tp1 = 0, tc0 = 0, tc1 = 0;
+        if (probe) { tp0 = __builtin_amdgcn_s_memrealtime(); tc0 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        if (phase_skew && wm == 1) AIM_BAR();
+        // One iteration = two K-tiles (even -> buffer 0, odd -> buffer 1) = four phases of
+        //   [ds_read fragments + 2 stage calls (4 LDS-DMA pieces)] ; barrier ; [32 MFMA] ; barrier.
+        // Stage order (each half goes out as soon as both wave groups are done reading it):
+        //   Ra: A halves of the odd tile `to`      Rb: B halves of even tile te+2   + vmcnt(4): odd tile landed
+        //   Rc: A halves of even tile te+2         Rd: B halves of odd tile to+2    + vmcnt(4): even tile te+2 landed
+        // RAW: a buffer is read in the phase AFTER the counted vmcnt + barrier that retires it (one more barrier
+        //      than the wave-group skew).  WAR: every read phase retires its ds_reads (lgkmcnt(0)) BEFORE its
+        //      barrier, and a half is restaged no earlier than the second phase after its last read.
+        // Slots >= nkp run into the NEXT tile's K-tiles (cross-tile prefetch).
         for (int it = 0; it < nkp / 2; ++it) {
             const int te = 2 * it, to = te + 1;
             const bool odd_live = to < nk;
-            // ---- even K-tile (buffer 0) ----
-            read_b(0); read_a(0, 0);
-            stage(1, 1, to);
-            AIM_BAR(); AIM_LGKM0();
-            mma(0, 0);
-            AIM_BAR();
-            stage(0, 2, te + 2);                    // phase 2
-            AIM_BAR();
-            mma(0, 2);
-            AIM_BAR();
-            read_a(0, 1);                           // phase 3
-            stage(0, 3, te + 2);
-            AIM_BAR(); AIM_LGKM0();
-            mma(1, 2);
-            AIM_BAR();
-            stage(0, 0, te + 2);                    // phase 4
-            AIM_VM6();
-            AIM_BAR();
-            mma(1, 0);
-            AIM_BAR();
-            // ---- odd K-tile (buffer 1) ----
-            if (odd_live) { read_b(1); read_a(1, 0); }
-            stage(0, 1, te + 2);
-            AIM_BAR(); AIM_LGKM0();
-            if (odd_live) mma(0, 0);
-            AIM_BAR();
-            stage(1, 2, to + 2);                    // phase 6
-            AIM_BAR();
-            if (odd_live) mma(0, 2);
-            AIM_BAR();
-            if (odd_live) read_a(1, 1);             // phase 7
-            stage(1, 3, to + 2);
-            AIM_BAR(); AIM_LGKM0();
-            if (odd_live) mma(1, 2);
-            AIM_BAR();
-            stage(1, 0, to + 2);                    // phase 8
-            AIM_VM6();
-            AIM_BAR();
-            if (odd_live) mma(1, 0);
-            AIM_BAR();
+#ifdef AIM_X_STAMPS
+            stamp_arm = (probe != nullptr) && blockIdx.x == 0 && probe_i == 1 && it == 2;
+#endif
+            AIM_STAMP(0);
+            read_b(0); read_a(0, 0);                               // ---- Ra
+            stage(1, 0, to); stage(1, 1, to);
+            AIM_LGKM0();
+            AIM_STAMP(1); AIM_BAR(); AIM_STAMP(2);
+            mma(0, 0); mma(0, 2);
+            AIM_STAMP(3); AIM_BAR(); AIM_STAMP(4);
+            read_a(0, 1);                                          // ---- Rb
+            stage(0, 2, te + 2); stage(0, 3, te + 2);
+            AIM_VM4();
+            AIM_LGKM0();
+            AIM_STAMP(5); AIM_BAR(); AIM_STAMP(6);
+            mma(1, 2); mma(1, 0);
+            AIM_STAMP(7); AIM_BAR(); AIM_STAMP(8);
+            if (odd_live) { read_b(1); read_a(1, 0); }             // ---- Rc
+            stage(0, 0, te + 2); stage(0, 1, te + 2);
+            AIM_LGKM0();
+            AIM_STAMP(9); AIM_BAR(); AIM_STAMP(10);
+            if (odd_live) { mma(0, 0); mma(0, 2); }
+            AIM_STAMP(11); AIM_BAR(); AIM_STAMP(12);
+            if (odd_live) read_a(1, 1);                            // ---- Rd
+            stage(1, 2, to + 2); stage(1, 3, to + 2);
+            AIM_VM4();
+            AIM_LGKM0();
+            AIM_STAMP(13); AIM_BAR(); AIM_STAMP(14);
+            if (odd_live) { mma(1, 2); mma(1, 0); }
+            AIM_STAMP(15); AIM_BAR(); AIM_STAMP(16);
         }
+#ifdef AIM_X_STAMPS
+        if (probe && blockIdx.x == 0 && probe_i == 1 && lane == 0 && (wave == 0 || wave == 4)) {
+            unsigned long long* sp = probe + (long long)(probe_cap - 32) * 4 + (wave == 4 ? 64 : 0);
+#pragma unroll
+            for (int i = 0; i < 17; ++i) sp[i] = stamps[i];
+        }
+#endif
         // Epilogue of this tile; the next tile's first K-tiles are already in flight / landed in the K-loop
         // images, so the scratch is separate (wave-private, no barrier needed).
+        if (phase_skew && wm == 0) AIM_BAR();
+        if (probe) { tp1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
         wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
+        if (probe) {        // diagnostics (aim_gemm_probe): per-tile timestamps of wave 0, 100 MHz ticks
+            const int slot = probe_i * (int)gridDim.x + (int)blockIdx.x;
+            if (tid == 0 && slot < probe_cap) {
+                probe[slot * 4 + 0] = (unsigned long long)blockIdx.x | ((tc1 - tc0) << 16);   // K-loop shader cycles
+                probe[slot * 4 + 1] = tp0;
+                probe[slot * 4 + 2] = tp1;
+                probe[slot * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            }
+            ++probe_i;
+        }
         cur = nxt;
         nxt = make_tile(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, wave, srow, schunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }
+
+unsigned long long* g_probe = nullptr;
+int g_probe_cap = 0;
 
 template <int EPI>
 int launch256(const GemmArgs& g, hipStream_t st) {
@@ -257,12 +318,21 @@ int launch256(const GemmArgs& g, hipStream_t st) {
     } else if (grid >= 8) {
         grid = (grid / 8) * 8;     // XCD-aware schedule wants a multiple of 8; smaller grids use plain round-robin
     }
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, ngroups);
+    static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, ngroups, phase_skew, g_probe, g_probe_cap);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }
 
 }  // namespace
+
+// diagnostics: while a buffer is set, every gemm256 launch records {workgroup, tile start, K-loop end, epilogue end}
+// (100 MHz ticks) per tile into buf[capacity][4]; pass null to switch it off
+extern "C" int aim_gemm_probe(void* buf, int capacity) {
+    g_probe = (unsigned long long*)buf;
+    g_probe_cap = buf ? capacity : 0;
+    return 0;
+}
 
 int aim_gemm256_launch(const GemmArgs& g, int epi, hipStream_t st) {
     AIM_CHECK_ARG((long long)256 * g.lda * 2 < 0x7fffffffLL && (long long)256 * g.ldw * 2 < 0x7fffffffLL, "gemm256: leading dimension too large");

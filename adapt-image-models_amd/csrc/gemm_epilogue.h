@@ -167,7 +167,11 @@ __device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, unsigned 
 }
 template <typename V>
 __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, V v) {
+#ifdef AIM_X_NOSTORE
+    asm volatile("" ::"v"(__builtin_bit_cast(u32x4, v)), "v"(voff));
+#else
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+#endif
 }
 // a running byte offset the compiler may not pre-compute for all 16 sub-passes (that costs 16 VGPRs and spills)
 __device__ __forceinline__ void epi_advance(unsigned& voff, unsigned step) {

@@ -12,7 +12,8 @@ class LibraryNotBuilt(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libaim_hip.so")
+    # AIM_HIP_LIB selects an experimental build of the same library (tools/ only); there is still no fallback
+    return os.environ.get("AIM_HIP_LIB") or os.path.join(_HERE, "libaim_hip.so")
 
 
 class GemmArgs(Structure):
@@ -41,6 +42,7 @@ SIGNATURES = {
     "aim_last_error": [],
     "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
     "aim_gemm_expsum_tiles": [I, I],
+    "aim_gemm_probe": [P, I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],

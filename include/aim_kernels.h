@@ -85,6 +85,11 @@ int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stre
 /* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
 int aim_gemm_expsum_tiles(int M, int N);
 
+/* Diagnostics (no reference counterpart): while `buf` (device memory, capacity x 4 uint64) is set, every
+ * large-tile GEMM launch records {workgroup, tile start, K-loop end, epilogue end} in 100 MHz ticks per
+ * processed tile.  Pass NULL to switch it off.  Used by tools/probe_gemm.py only. */
+int aim_gemm_probe(void* buf, int capacity);
+
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM for the (trainable) adapters:
  *   dW[n][k] += sum_m G[m][n] * A[m][k]      db[n] += sum_m G[m][n]        (fp32 atomics)
