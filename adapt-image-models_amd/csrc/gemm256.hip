@@ -42,7 +42,7 @@ namespace {
 constexpr int HT = 128 * 64 * 2;        // half-tile bytes
 constexpr int BUF = 4 * HT;             // one K-tile buffer: A_lo, A_hi, B_lo, B_hi
 constexpr int OFF_A = 0, OFF_B = 2 * HT;
-constexpr int LDS_BYTES = 2 * BUF + 8 * EPI_SCRATCH;   // K-loop images + 8 wave-private epilogue scratches
+constexpr int LDS_BYTES = 2 * BUF + 8 * EPI_SCRATCH;   // K-loop images + 8 wave-private row-factor tables
 
 // Per-tile staging state: buffer descriptors of the tile's A rows / W rows and the per-lane row offsets.
 struct TileSrc {
@@ -190,8 +190,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         __builtin_amdgcn_s_setprio(0);
     };
 #define AIM_BAR() __builtin_amdgcn_s_barrier()
-#define AIM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define AIM_VM4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+// s_waitcnt as builtins (simm16: vmcnt[3:0] | expcnt<<4 | lgkmcnt<<8 | vmcnt[5:4]<<14) so the compiler's own scoreboard
+// sees them.  hipcc still flushes `vmcnt(0)` at the K-loop header while LDS-DMA is in flight (it is gone only when the
+// stage calls are compiled out); stamped, that costs ~40 of an iteration's ~5500 cycles.
+#define AIM_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
+#define AIM_VM4() __builtin_amdgcn_s_waitcnt(0x0F74)
 
     // prologue (first tile only): K-tile 0 complete, three half-tiles of K-tile 1 in flight
     stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);

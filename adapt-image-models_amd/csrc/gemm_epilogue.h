@@ -144,6 +144,11 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 // Per-row factors (af/at/bt) are computed once per tile into a wave-private LDS table, so the
 // sub-passes themselves contain no load besides the prefetched resid / aux rows.
 // Null optional inputs (bias, resid, vec, af, at, bt) get a zero-length resource and read as 0.
+//
+// Measured and rejected: re-tiling in registers (v_permlane32_swap + v_permlane16_swap give a lane 8 consecutive
+// columns, no LDS round trip).  Its stores cover 16 rows x 64 B instead of 8 rows x 128 B (fp32: 4 rows x 256 B
+// here), i.e. half cache lines: BF16 epilogue 3.9 -> 3.4 us but F32 12 -> 17 us, DACT 11 -> 13 us and a longer
+// store drain in the next tile's K-loop; whole step 1012 -> 962 clips/s.  Full-line row segments win.
 // ------------------------------------------------------------------------------------------------
 constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad
 constexpr int EPI_ROWFAC = 8 * EPI_RS;           // offset of the per-row factor table: 128 rows x {rs, vs}
@@ -192,7 +197,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             for (int j = 0; j < 4; ++j)
                 *(AIM_LDS f32x4*)(scr + (frow & 7) * EPI_RS + (j * 16 + fq * 4) * 4) = acc[mt][j];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // writes landed before other lanes read them
+#ifdef AIM_X_EPIWAIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        // No wait here: a wave's DS instructions execute in issue order, so the reads below see these writes.  The
+        // statement only pins the COMPILER's order (it once hoisted the reads above the exec-masked writes).
+        asm volatile("" ::: "memory");
+#endif
     };
     const bool rowf = g.af || g.at || g.vec;
     const int rows_left = min(g.M - m_base, 128), cols_left = g.N - n_base;   // may be <= 0: every lane out of range
