@@ -14,11 +14,29 @@
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
 
+#ifdef AIM_X_STAMPS      // diagnostic build only (tools/probe_attn.py): shader-clock stamps of one workgroup's waves
+static unsigned long long* g_attn_probe = nullptr;
+extern "C" int aim_attn_probe(void* buf) { g_attn_probe = (unsigned long long*)buf; return 0; }
+#define ATT_STAMP(i) do { if (probe && blockIdx.x == 3000) { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ATT_STAMP(i)
+#endif
+
 namespace {
 
 template <int NKT>  // number of 16-key tiles (even)
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          float* __restrict__ lse, int N, int H) {
+                                                          float* __restrict__ lse, int N, int H
+#ifdef AIM_X_STAMPS
+                                                          , unsigned long long* probe
+#endif
+) {
+#ifdef AIM_X_STAMPS
+    unsigned long long stamps[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) stamps[i] = 0;
+#endif
+    ATT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
     AIM_LDS char* sV = sK + NKT * 16 * 128;
@@ -53,13 +71,22 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP(1);
     __syncthreads();
+    ATT_STAMP(2);
 
     for (int qt = wave; qt < nqt; qt += NW) {
         // the K/V fragments do not depend on qt: without this fence LICM hoists all 28 K fragments
         // (112 VGPRs) out of the loop and the kernel spills
         asm volatile("" ::: "memory");
         const int q = qt * 16 + frow;
+#ifdef AIM_X_STAMPS
+        const int sb = qt < NW ? 3 : 9;
+#define ATT_STAMPQ(i) do { if (sb == 3) ATT_STAMP(3 + i); else ATT_STAMP(9 + i); } while (0)
+#else
+#define ATT_STAMPQ(i)
+#endif
+        ATT_STAMPQ(0);
         f32x4 s[NKT];
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -70,6 +97,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
+        ATT_STAMPQ(1);
         // prefetch the next query tile of this wave
         if (qt + NW < nqt) {
             const int qn = (qt + NW) * 16 + frow;
@@ -106,6 +134,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
         const float inv = 1.0f / sum;
         if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx * 0.125f + __logf(sum);
 
+        ATT_STAMPQ(2);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -134,19 +163,32 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
             }
         }
+        ATT_STAMPQ(3);
         if (q < N) {
             bf16_t* op = out + ((long long)bt * N + q) * D + h * 64 + fq * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 *(bf16x4*)(op + dt * 16) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
         }
+        ATT_STAMPQ(4);
     }
+#ifdef AIM_X_STAMPS
+    stamps[15] = __builtin_amdgcn_s_memtime();
+    if (probe && blockIdx.x == 3000 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) probe[wave * 16 + i] = stamps[i];
+    }
+#endif
 }
 
 template <int NKT>
 int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
     hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, N, H);
+                       (bf16_t*)out, lse, N, H
+#ifdef AIM_X_STAMPS
+                       , g_attn_probe
+#endif
+    );
     AIM_CHECK_LAUNCH("aim_attn_fwd");
     return 0;
 }
