@@ -20,6 +20,9 @@
 
 namespace {
 
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float C2 = 0.125f * LOG2E;      // 1/sqrt(dh) * log2(e): probabilities are recomputed in base 2
+
 __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N,
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
         }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        const float L = lse[((long long)bt * H + h) * N + qc];
+        // exp(s/8 - L) = exp2(s * C2 - L2): one fma + one v_exp per score
+        const float L2 = lse[((long long)bt * H + h) * N + qc] * LOG2E;
         if (fq == 0 && q < N) delta[((long long)bt * H + h) * N + q] = dl;
 
         f32x4 dq[4];
@@ -86,11 +90,12 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);
                 }
+                // No key mask: rows of K and V past N are zero-filled in LDS, so such a key has a finite p and its dS
+                // meets a zero K^T row in the dQ product.  The 1/sqrt(dh) factor of dS is applied once to dQ.
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = t * 16 + fq * 4 + e;
-                    const float p = key < N ? __expf(s[e] * 0.125f - L) : 0.f;
-                    dsf[u * 4 + e] = (bf16_t)(p * (dp[e] - dl) * 0.125f);
+                    const float p = __builtin_amdgcn_exp2f(s[e] * C2 - L2);
+                    dsf[u * 4 + e] = (bf16_t)(p * (dp[e] - dl));
                 }
             }
 #pragma unroll
@@ -111,7 +116,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
         if (q < N) {
             bf16_t* op = dqkv + ((long long)bt * N + q) * ld + h * 64 + fq * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = pack4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]);
+            for (int dt = 0; dt < 4; ++dt)
+                *(bf16x4*)(op + dt * 16) = pack4(dq[dt][0] * 0.125f, dq[dt][1] * 0.125f, dq[dt][2] * 0.125f, dq[dt][3] * 0.125f);
         }
     }
 }
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             stage_piece(rO, sO + p * 1024, qr < N ? (unsigned)((qr * D + schunk * 8) * 2) : AIM_OOB);
         }
         for (int i = tid; i < nq32; i += 256) {
-            sL[i] = i < N ? lse[((long long)bt * H + h) * N + i] : 0.f;
+            sL[i] = i < N ? lse[((long long)bt * H + h) * N + i] * LOG2E : 0.f;
             sD[i] = i < N ? delta[((long long)bt * H + h) * N + i] : 0.f;
         }
     }
@@ -195,12 +201,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[u][ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[ks], vf[u][ks], dp, 0, 0, 0);
                     }
-                    const bool kin = (kp * 32 + u * 16 + frow) < N;
+                    // No masks: a key past N is a clamped duplicate whose dK / dV rows are never stored; a query past N
+                    // has zero-filled Q and dO rows (and L = delta = 0), so it adds nothing to dK or dV.
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float p = kin ? __expf(s[e] * 0.125f - Lr[e]) : 0.f;
+                        const float p = __builtin_amdgcn_exp2f(s[e] * C2 - Lr[e]);
                         pf[u][w * 4 + e] = (bf16_t)p;
-                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - Dr[e]) * 0.125f);
+                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - Dr[e]));
                     }
                 }
             }
@@ -236,7 +243,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 bf16_t* op = dqkv + ((long long)bt * N + key) * ld + h * 64 + fq * 4;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    *(bf16x4*)(op + D + dt * 16) = pack4(dk[dt][u][0], dk[dt][u][1], dk[dt][u][2], dk[dt][u][3]);
+                    *(bf16x4*)(op + D + dt * 16) =
+                        pack4(dk[dt][u][0] * 0.125f, dk[dt][u][1] * 0.125f, dk[dt][u][2] * 0.125f, dk[dt][u][3] * 0.125f);
                     *(bf16x4*)(op + 2 * D + dt * 16) = pack4(dv[dt][u][0], dv[dt][u][1], dv[dt][u][2], dv[dt][u][3]);
                 }
             }

@@ -24,7 +24,10 @@ extern "C" int aim_attn_probe(void* buf) { g_attn_probe = (unsigned long long*)b
 
 namespace {
 
-template <int NKT>  // number of 16-key tiles (even)
+// NKT: number of 16-key tiles of the LDS images (even).  NFULL: key tiles below NFULL are known to lie entirely below N,
+// so only tiles >= NFULL carry masking code (N = 197: NKT = 14, NFULL = 12; masking every tile costs ~1.5x the
+// softmax's useful vector instructions in compares, selects and spilled condition masks).
+template <int NKT, int NFULL>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int N, int H
 #ifdef AIM_X_STAMPS
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            if (t * 16 + 16 > N) {
+            if (t >= NFULL) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (t * 16 + fq * 4 + e >= N) s[t][e] = -INFINITY;
@@ -181,9 +184,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
 #endif
 }
 
-template <int NKT>
-int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
-    hipLaunchKernelGGL(attn_fwd_kernel<NKT>, dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
+template <int NKT, int NFULL>
+int launch_nf(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<NKT, NFULL>), dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
                        (bf16_t*)out, lse, N, H
 #ifdef AIM_X_STAMPS
                        , g_attn_probe
@@ -191,6 +194,13 @@ int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H,
     );
     AIM_CHECK_LAUNCH("aim_attn_fwd");
     return 0;
+}
+
+// masking code only on the last two key tiles when N reaches into them, on every tile otherwise
+template <int NKT>
+int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
+    if ((N >> 4) >= NKT - 2) return launch_nf<NKT, NKT - 2>(qkv, out, lse, BT, N, H, st);
+    return launch_nf<NKT, 0>(qkv, out, lse, BT, N, H, st);
 }
 
 }  // namespace
