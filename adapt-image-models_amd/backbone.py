@@ -176,41 +176,114 @@ def _empty(shape, dtype, dev):
 # B*T = 512 rows) occupies a few CUs for ~100 us.  It runs on a second HIP stream beside the spatial
 # attention kernels, which do not depend on it; the two are joined with events before `lamda`.
 _SIDE = {}
+_DETACHED = {}
 _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
+_LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
+_LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
+_DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
+_RESERVE_CUS = int(os.environ.get("AIM_RESERVE_CUS", "0"))      # CUs the persistent GEMMs leave free inside a fork
 
 
 class _Fork:
-    """``with _Fork(dev) as f:`` runs the body on the side stream after everything queued on the current
-    stream so far; ``f.join()`` makes the current stream wait for the body."""
+    """Side-stream sections beside the current (main) stream.
+
+    ``with f.side():`` queues its body on the side stream, ordered after everything queued on the main stream when
+    the section is entered (the first section) or when ``f.sync_side_to_main()`` was last called.  ``f.join()``
+    makes the main stream wait for all sections.  With ``AIM_SIDE_STREAM=0`` every section simply runs inline."""
 
     def __init__(self, dev):
         self.enabled = _USE_SIDE
+        self.dev = dev
+        self.started = False
         if self.enabled:
             key = (dev.type, dev.index)
             if key not in _SIDE:
-                _SIDE[key] = torch.cuda.Stream(device=dev)
-            self.side = _SIDE[key]
+                # high priority: the side stream carries a dozen tiny kernels that the main stream later waits for
+                _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AIM_SIDE_PRIORITY", "-1")))
+            self.side_stream = _SIDE[key]
             self.main = torch.cuda.current_stream(dev)
 
-    def __enter__(self):
+    def sync_side_to_main(self):
+        """The side stream waits for everything queued on the main stream so far."""
         if self.enabled:
             ev = torch.cuda.Event()
             ev.record(self.main)
-            self.side.wait_event(ev)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
+            self.side_stream.wait_event(ev)
+
+    def side(self):
+        fork = self
+
+        class _Section:
+            def __enter__(self_inner):
+                if fork.enabled:
+                    if not fork.started:
+                        fork.started = True
+                        if _RESERVE_CUS:    # persistent GEMMs launched until join() leave room for the side stream's kernels
+                            ops.gemm_reserve_cus(_RESERVE_CUS)
+                        fork.sync_side_to_main()
+                    self_inner.ctx = torch.cuda.stream(fork.side_stream)
+                    self_inner.ctx.__enter__()
+                return fork
+
+            def __exit__(self_inner, *exc):
+                if fork.enabled:
+                    self_inner.ctx.__exit__(*exc)
+                return False
+
+        return _Section()
+
+    # ``with _Fork(dev) as f:`` = one side section
+    def __enter__(self):
+        self._sec = self.side()
+        return self._sec.__enter__()
 
     def __exit__(self, *exc):
-        if self.enabled:
-            self.done = torch.cuda.Event()
-            self.done.record(self.side)
-            self.ctx.__exit__(*exc)
-        return False
+        return self._sec.__exit__(*exc)
+
+    def run_detached(self, calls: list, keep: list):
+        """Run ``calls`` (closures launching kernels) after the side stream's work so far, on a third stream that nothing
+        waits for until ``join_detached``.  ``keep`` receives the closures so that the tensors they captured (allocated
+        on other streams) outlive their use."""
+        if not calls:
+            return
+        if not (self.enabled and _DETACH_WGRAD):
+            ctx = self.side() if self.enabled else None
+            if ctx is not None:
+                with ctx:
+                    for f in calls:
+                        f()
+            else:
+                for f in calls:
+                    f()
+            return
+        key = (self.dev.type, self.dev.index)
+        if key not in _DETACHED:
+            _DETACHED[key] = torch.cuda.Stream(device=self.dev)
+        w = _DETACHED[key]
+        ev = torch.cuda.Event()
+        ev.record(self.side_stream)
+        w.wait_event(ev)
+        with torch.cuda.stream(w):
+            for f in calls:
+                f()
+        keep.extend(calls)
+
+    @staticmethod
+    def join_detached(dev):
+        """The current stream waits for everything queued by ``run_detached``."""
+        w = _DETACHED.get((dev.type, dev.index))
+        if w is not None:
+            ev = torch.cuda.Event()
+            ev.record(w)
+            torch.cuda.current_stream(dev).wait_event(ev)
 
     def join(self):
-        if self.enabled:
-            self.main.wait_event(self.done)
+        if self.enabled and self.started:
+            if _RESERVE_CUS:
+                ops.gemm_reserve_cus(0)
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+            self.main.wait_event(done)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -252,22 +325,30 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
         crs = _empty((BT, D), F32, dev)
         ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
-    # spatial attention (:264) and the ow statistic of lamda (:149-151) -- independent of the class-token path
-    ao = _empty((M, D), BF16, dev)
-    lse = _empty((BT, H, N), F32, dev)
-    ops.attn_fwd(qkv, ao, lse, BT, N, H)
+    # main stream: the ow statistic of lamda (:149-151), then the spatial attention (:264) -- independent of the class path
     nt = ops.expsum_tiles(N, N)
     part = _empty((BT, nt, 2), F32, dev)
     ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
              stride_w=N * 3 * D, scale=0.125)
+    def lamda_chain():
+        # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
+        lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
+        ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125)
+        # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
+        sin = _empty((BT, D), BF16, dev)
+        ops.scale_rows(crs, lam, y=sin)
+        return (lam, oml, sin) + _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, dev, out_f32=True)
+
+    if _LAMBDA_ON_SIDE:               # the chain runs beside the spatial attention instead of after it
+        fork.sync_side_to_main()      # it needs `part`
+        with fork.side():
+            lam, oml, sin, sv, s_pre, s_h = lamda_chain()
+    ao = _empty((M, D), BF16, dev)
+    lse = _empty((BT, H, N), F32, dev)
+    ops.attn_fwd(qkv, ao, lse, BT, N, H)
     fork.join()
-    # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
-    lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
-    ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125)
-    # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
-    sin = _empty((BT, D), BF16, dev)
-    ops.scale_rows(crs, lam, y=sin)
-    sv, s_pre, s_h = _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, dev, out_f32=True)
+    if not _LAMBDA_ON_SIDE:
+        lam, oml, sin, sv, s_pre, s_h = lamda_chain()
     # x1 = x + (1 - lamda) * out_proj(ao) + drop_path(scale * s_vec)
     x1 = _empty((M, D), F32, dev)
     ops.gemm(ao, fz.Wo, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
@@ -293,18 +374,19 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     return x2, ctx
 
 
-def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, dev, need_dx_bf16: bool):
-    """Backward of an adapter on a few rows; accumulates its 4 parameter gradients, returns d(input)."""
-    ops.wgrad(dout_bf, h, grads["D_fc2.weight"], grads["D_fc2.bias"])
+def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, dev, need_dx_bf16: bool, later: list):
+    """Backward of an adapter on a few rows; returns d(input).  Its 4 parameter gradients are not on the gradient
+    path: the two wgrad calls are appended to ``later`` (run by the caller off the critical stream)."""
+    later.append(lambda: ops.wgrad(dout_bf, h, grads["D_fc2.weight"], grads["D_fc2.bias"]))
     dpre = _empty((rows, r), BF16, dev)
     ops.gemm(dout_bf, ad.W2T, ops.EPI_DACT, dpre, aux=pre, act=ops.ACT_GELU)
-    ops.wgrad(dpre, a_in, grads["D_fc1.weight"], grads["D_fc1.bias"])
+    later.append(lambda: ops.wgrad(dpre, a_in, grads["D_fc1.weight"], grads["D_fc1.bias"]))
     din = _empty((rows, D), BF16 if need_dx_bf16 else F32, dev)
     ops.gemm(dpre, ad.W1T, ops.EPI_BF16 if need_dx_bf16 else ops.EPI_F32, din)
     return din
 
 
-def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T, N, H):
+def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T, N, H, keep: Optional[list] = None):
     """dyb = d(loss)/d(x2) [M, D] -> d(loss)/d(x); adapter grads accumulated into ``grads``.
 
     The residual-stream GRADIENT is carried in bf16 (one tensor serves as the running residual gradient and
@@ -331,6 +413,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     del dxn
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
+    later: list = []       # the class-token adapters' weight gradients: nobody downstream waits for them
     with _Fork(dev) as fork:
         dsv = _empty((BT, D), F32, dev)
         ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
@@ -338,7 +421,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
         dsv_b = _empty((BT, D), BF16, dev)
         ops.cast_bf16(dsv, dsv_b)
         dsin = _adapter_bwd_small(dsv_b, adp["S_Adapter"], c["sin"], c["s_pre"], c["s_h"], grads["S_Adapter"], BT, r,
-                                  D, dev, need_dx_bf16=False)
+                                  D, dev, need_dx_bf16=False, later=later)
         dcrs = _empty((BT, D), BF16, dev)
         ops.scale_rows(dsin, c["lam"], y=dcrs)
         dvx = _empty((BT, D), BF16, dev)
@@ -347,22 +430,39 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
         ops.gemm(dvx, fz.WqkvT[:, 2 * D:], ops.EPI_BF16, dxt)
         # T_Adapter and out_proj of the temporal attention over class tokens
         dta = _adapter_bwd_small(dxt, adp["T_Adapter"], c["ta"], c["t_pre"], c["t_h"], grads["T_Adapter"], BT, r, D,
-                                 dev, need_dx_bf16=True)
+                                 dev, need_dx_bf16=True, later=later)
         dot = _empty((BT, D), BF16, dev)
         ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
-    # ... beside the spatial attention backward on the main stream
+        # the class rows' share of d(qkv) and its QKV dgrad stay on the side stream: the main stream's big dgrad GEMM
+        # below does not wait for the class-token chain
+        if _LATE_JOIN:
+            dqkv_cls = _empty((BT, 3 * D), BF16, dev)
+            ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv_cls, B, T, N, H, compact=True)
+            dxl_cls = _empty((BT, D), F32, dev)
+            ops.gemm(dqkv_cls, fz.WqkvT, ops.EPI_F32, dxl_cls)
+    if keep is None:       # stand-alone use: the weight gradients are complete when this function returns
+        keep = []
+        fork.run_detached(later, keep)
+        _Fork.join_detached(dev)
+    else:
+        fork.run_detached(later, keep)
+    # ... beside the spatial attention backward and the fused QKV dgrad on the main stream
     dao = _empty((M, D), BF16, dev)
     ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N)
     dqkv = _empty((M, 3 * D), BF16, dev)
     delta = _empty((BT, H, N), F32, dev)
     ops.attn_bwd(c["qkv"], c["ao"], dao, c["lse"], delta, dqkv, BT, N, H)
     del dao
-    fork.join()
-    ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)     # adds the class rows' dq/dk/dv
-    # ---- fused QKV projection (dgrad) and ln_1
+    if not _LATE_JOIN:      # (A/B switch) join first and add the class rows into d(qkv) itself
+        fork.join()
+        ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)
     dxl = _empty((M, D), BF16, dev)
     ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
     del dqkv
+    if _LATE_JOIN:
+        fork.join()
+        ops.add_rows(dxl, N * D, dxl_cls)       # class rows: rows n == 0 of every frame
+    # ---- ln_1
     dxb = _empty((M, D), BF16, dev)
     ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
     return dxb
@@ -471,14 +571,17 @@ class _BackboneFn(torch.autograd.Function):
         dxb = torch.zeros((M, D), dtype=BF16, device=dev)
         ops.layernorm_bwd(dy, s["xL"], s["gw"], s["meanp"], s["rstdp"], BT, D, lddy=D, ldx=N * D, lddx=N * D,
                           dx_bf16=dxb, dgamma=dgw, dbeta=dgb)
+        keep: list = []        # tensors the detached weight-gradient stream still reads; dropped after join_detached
         for i in reversed(range(L)):
-            dxb = _block_backward(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H)
+            dxb = _block_backward(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
             s["ctxs"][i] = None
         dtmp = buf(0)
         ops.embed_bwd(dxb, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"],
                       dtmp.view(T, D), B, T, N, D)
         grads_out[0] = dtmp.view(1, T, D)
         grads_out[1], grads_out[2] = dgw, dgb
+        _Fork.join_detached(dev)       # every weight gradient is in place before autograd hands them on
+        keep.clear()
         for k, p_ in enumerate(params):
             if not p_.requires_grad or in_place[k]:
                 grads_out[k] = None

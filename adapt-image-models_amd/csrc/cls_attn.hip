@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void cls_attn_fwd_kernel(const bf16_t* __restri
 
 __global__ __launch_bounds__(64) void cls_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ probs,
                                                           const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
-                                                          int T, int N, int H) {
+                                                          int T, int N, int H, int compact) {
     __shared__ float sq[TMAX][65], sk[TMAX][65], sv[TMAX][65], sdo[TMAX][65], sp[TMAX][TMAX + 1], sds[TMAX][TMAX + 1];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * 64, ld = 3 * D, lane = threadIdx.x;
@@ -101,10 +101,17 @@ __global__ __launch_bounds__(64) void cls_attn_bwd_kernel(const bf16_t* __restri
             dk += sds[u][t] * sq[u][lane];
             dv += sp[u][t] * sdo[u][lane];
         }
-        bf16_t* r = dqkv + ((long long)(b * T + t) * N) * ld + h * 64 + lane;
-        r[0] = (bf16_t)((float)r[0] + dq);
-        r[D] = (bf16_t)((float)r[D] + dk);
-        r[2 * D] = (bf16_t)((float)r[2 * D] + dv);
+        if (compact) {      // dqkv is [B*T, 3D]: the class rows' contribution alone
+            bf16_t* r = dqkv + (long long)(b * T + t) * ld + h * 64 + lane;
+            r[0] = (bf16_t)dq;
+            r[D] = (bf16_t)dk;
+            r[2 * D] = (bf16_t)dv;
+        } else {            // dqkv is the spatial attention's [B*T*N, 3D]: add into its class rows
+            bf16_t* r = dqkv + ((long long)(b * T + t) * N) * ld + h * 64 + lane;
+            r[0] = (bf16_t)((float)r[0] + dq);
+            r[D] = (bf16_t)((float)r[D] + dk);
+            r[2 * D] = (bf16_t)((float)r[2 * D] + dv);
+        }
     }
 }
 
@@ -172,11 +179,11 @@ extern "C" int aim_cls_attn_fwd(const aim_bf16* qkv, aim_bf16* out_cls, float* p
 }
 
 extern "C" int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout_cls, aim_bf16* dqkv,
-                                int B, int T, int N, int H, void* stream) {
+                                int compact, int B, int T, int N, int H, void* stream) {
     AIM_CHECK_ARG(B > 0 && T > 0 && T <= TMAX && N > 0 && H > 0, "cls_attn_bwd: unsupported shape B=%d T=%d (T <= 32)", B, T);
     AIM_CHECK_ARG(qkv && probs && dout_cls && dqkv, "cls_attn_bwd: null pointer");
     hipLaunchKernelGGL(cls_attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qkv, probs,
-                       (const bf16_t*)dout_cls, (bf16_t*)dqkv, T, N, H);
+                       (const bf16_t*)dout_cls, (bf16_t*)dqkv, T, N, H, compact);
     AIM_CHECK_LAUNCH("aim_cls_attn_bwd");
     return 0;
 }

@@ -524,6 +524,28 @@ extern "C" int aim_cast_multi(const aim_cast_desc* table_dev, int n, void* strea
     return 0;
 }
 
+// dst[r * dst_row_stride + c] += src[r * C + c]: the class rows' share of a gradient, produced on the side stream,
+// folded into the token-major bf16 tensor on the main one
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ dst, long long dst_row_stride,
+                                                       const float* __restrict__ src, int R, int C) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long long)R * C) return;
+    const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+    bf16x4* d = (bf16x4*)(dst + r * dst_row_stride + c);
+    const f32x4 a = *(const f32x4*)(src + i);
+    const bf16x4 o = *d;
+    *d = pack4((float)o[0] + a[0], (float)o[1] + a[1], (float)o[2] + a[2], (float)o[3] + a[3]);
+}
+
+extern "C" int aim_add_rows_bf16(aim_bf16* dst, int64_t dst_row_stride, const float* src, int R, int C, void* stream) {
+    AIM_CHECK_ARG(R > 0 && C > 0 && (C % 4) == 0 && (dst_row_stride % 4) == 0 && dst && src, "add_rows: bad arguments");
+    const long long n = (long long)R * C / 4;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst,
+                       (long long)dst_row_stride, src, R, C);
+    AIM_CHECK_LAUNCH("aim_add_rows_bf16");
+    return 0;
+}
+
 extern "C" int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream) {
     AIM_CHECK_ARG(R > 0 && C > 0 && x && s && (y || y_f32), "scale_rows: bad arguments");
     const long long n = (long long)R * C;

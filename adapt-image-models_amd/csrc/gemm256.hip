@@ -301,6 +301,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 
 unsigned long long* g_probe = nullptr;
 int g_probe_cap = 0;
+int g_reserve_cus = 0;      // CUs the persistent grid leaves free (aim_gemm_reserve_cus)
 
 template <int EPI>
 int launch256(const GemmArgs& g, hipStream_t st) {
@@ -310,7 +311,10 @@ int launch256(const GemmArgs& g, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    int grid = tiles < aim_num_cus() ? tiles : aim_num_cus();
+    // a persistent grid that fills every CU starves whatever runs beside it on another stream: the caller can keep a few
+    // CUs out of the grid while such work is in flight
+    const int cus = aim_num_cus() - g_reserve_cus > 8 ? aim_num_cus() - g_reserve_cus : 8;
+    int grid = tiles < cus ? tiles : cus;
     // column groups: keep each group's weight slice (+ streaming A) inside an XCD's 4 MiB L2
     int ngroups = 1;
     static const int force_groups = [] { const char* e = getenv("AIM_GEMM_GROUPS"); return e ? atoi(e) : 0; }();
@@ -328,6 +332,11 @@ int launch256(const GemmArgs& g, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int aim_gemm_reserve_cus(int n) {
+    g_reserve_cus = n > 0 ? n : 0;
+    return 0;
+}
 
 // diagnostics: while a buffer is set, every gemm256 launch records {workgroup, tile start, K-loop end, epilogue end}
 // (100 MHz ticks) per tile into buf[capacity][4]; pass null to switch it off

@@ -43,6 +43,7 @@ SIGNATURES = {
     "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
     "aim_gemm_expsum_tiles": [I, I],
     "aim_gemm_probe": [P, I],
+    "aim_gemm_reserve_cus": [I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
@@ -50,7 +51,7 @@ SIGNATURES = {
     "aim_attn_fwd": [P, P, P, I, I, I, P],
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
-    "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, P],
+    "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, I, P],
     "aim_lambda": [P, P, I, P, I, P, P, I, I, I, F, P],
     "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],
     "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P, L, P],
     "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
+    "aim_add_rows_bf16": [P, L, P, I, I, P],
     "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],
     "aim_cast_multi": [P, I, P],
 }

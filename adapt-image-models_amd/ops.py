@@ -154,6 +154,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=No
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
 
 
+def gemm_reserve_cus(n: int):
+    """Persistent GEMM grids leave ``n`` CUs free until called again with 0 (see aim_gemm_reserve_cus)."""
+    check(load_library().aim_gemm_reserve_cus(int(n)), "aim_gemm_reserve_cus")
+
+
 def attn_fwd(qkv, out, lse, BT, N, H):
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(lse, F32, "lse")
     check(load_library().aim_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BT, N, H, _stream()),
@@ -173,10 +178,11 @@ def cls_attn_fwd(qkv, out_cls, probs, B, T, N, H):
                                           _stream()), "aim_cls_attn_fwd")
 
 
-def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H):
+def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H, compact: bool = False):
+    """compact=False: add into the class rows of dqkv [B*T*N, 3D]; compact=True: write dqkv [B*T, 3D]."""
     _chk(qkv, BF16, "qkv"); _chk(dout_cls, BF16, "dout_cls"); _chk(dqkv, BF16, "dqkv"); _chk(probs, F32, "probs")
     check(load_library().aim_cls_attn_bwd(qkv.data_ptr(), probs.data_ptr(), dout_cls.data_ptr(), dqkv.data_ptr(),
-                                          B, T, N, H, _stream()), "aim_cls_attn_bwd")
+                                          int(compact), B, T, N, H, _stream()), "aim_cls_attn_bwd")
 
 
 def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale):
@@ -250,6 +256,14 @@ def scale_rows(x, s, y=None, y_f32=None):
     R, C = x.shape
     check(load_library().aim_scale_rows(x.data_ptr(), s.data_ptr(), _p(y), _p(y_f32), R, C, _stream()),
           "aim_scale_rows")
+
+
+def add_rows(dst, dst_row_stride: int, src):
+    """dst[r * dst_row_stride + c] += src[r, c]  (bf16 += fp32)."""
+    _chk(dst, BF16, "dst"); _chk(src, F32, "src")
+    R, C = src.shape
+    check(load_library().aim_add_rows_bf16(dst.data_ptr(), int(dst_row_stride), src.data_ptr(), R, C, _stream()),
+          "aim_add_rows_bf16")
 
 
 def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):

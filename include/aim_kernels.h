@@ -85,6 +85,11 @@ int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stre
 /* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
 int aim_gemm_expsum_tiles(int M, int N);
 
+/* The large-tile GEMM is persistent (one workgroup per CU).  While `n` > 0, its grid leaves `n` CUs free so that
+ * kernels queued on ANOTHER stream (the class-token chain beside the spatial attention) are not starved.  Host-side
+ * state read at launch time; call with 0 to restore.  No reference counterpart. */
+int aim_gemm_reserve_cus(int n);
+
 /* Diagnostics (no reference counterpart): while `buf` (device memory, capacity x 4 uint64) is set, every
  * large-tile GEMM launch records {workgroup, tile start, K-loop end, epilogue end} in 100 MHz ticks per
  * processed tile.  Pass NULL to switch it off.  Used by tools/probe_gemm.py only. */
@@ -131,11 +136,12 @@ int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_bf16* dout,
  * Temporal attention over the T class tokens of each clip -- vit_clip.py:220-224 with
  * attention() :139-156 at seq = T, batch = B.  Reads the class rows (token 0) of qkv.
  *   out_cls [B*T, D] bf16 ; probs [B, H, T, T] f32 (saved for backward)
- *   bwd: ADDS dq/dk/dv of the class rows into dqkv [BT*N, 3*D] (bf16, rows n == 0).
+ *   bwd: compact == 0: ADDS dq/dk/dv of the class rows into dqkv [BT*N, 3*D] (bf16, rows n == 0);
+ *        compact != 0: WRITES them to dqkv [B*T, 3*D] (the class rows' share alone, for a separate dgrad).
  * ------------------------------------------------------------------------------------------ */
 int aim_cls_attn_fwd(const aim_bf16* qkv, aim_bf16* out_cls, float* probs, int B, int T, int N, int H,
                      void* stream);
-int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout_cls, aim_bf16* dqkv,
+int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout_cls, aim_bf16* dqkv, int compact,
                      int B, int T, int N, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -179,6 +185,9 @@ int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, const float* at
 int aim_cast_bf16(const float* src, aim_bf16* dst, int R, int C, int transpose, int ldd /* dst row stride, 0 = dense */,
                   void* stream);
 int aim_scale_rows(const float* x, const float* s, aim_bf16* y, float* y_f32, int R, int C, void* stream);
+/* dst[r * dst_row_stride + c] += src[r * C + c] (bf16 += fp32): folds the class rows' gradient share, computed apart on
+ * the side stream, into a token-major tensor (dst_row_stride = N * D selects the class rows). */
+int aim_add_rows_bf16(aim_bf16* dst, int64_t dst_row_stride, const float* src, int R, int C, void* stream);
 
 /* A table of casts in ONE launch: dst = bf16(src) or bf16(src^T) with row stride ldd, for the ~150 small
  * adapter tensors that must be re-staged as bf16 GEMM operands after every optimizer step.  The table

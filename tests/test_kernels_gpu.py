@@ -235,6 +235,13 @@ def test_cls_attn(B, T, N, H):
     dqkv = base.clone()
     ops.cls_attn_bwd(qkv, probs, do, dqkv, B, T, N, H)
     close(dqkv, base.float() + x.grad, 2e-2, 2e-2, "cls dqkv (accumulated into class rows)")
+    # compact mode: the class rows' share alone, [BT, 3D]; folded back by add_rows
+    comp = torch.full((BT, 3 * D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.cls_attn_bwd(qkv, probs, do, comp, B, T, N, H, compact=True)
+    close(comp, x.grad.reshape(BT, N, 3 * D)[:, 0], 2e-2, 2e-2, "cls dqkv (compact)")
+    tgt = base.clone()
+    ops.add_rows(tgt, N * 3 * D, comp.float())
+    close(tgt, base.float() + x.grad, 2e-2, 2e-2, "add_rows(class rows)")
 
 
 def test_lambda():
