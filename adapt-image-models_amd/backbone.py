@@ -181,6 +181,7 @@ _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
 _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
+_DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _RESERVE_CUS = int(os.environ.get("AIM_RESERVE_CUS", "0"))      # CUs the persistent GEMMs leave free inside a fork
 
 
@@ -398,12 +399,22 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     r, H4 = fz.r, 4 * D
     gm = grads["MLP_Adapter"]
     # ---- MLP + MLP_Adapter: x2 = x1 + [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2
-    ops.colsum(dyb, gm["D_fc2.bias"], at=c["dms2"], ntok=N)
-    ops.wgrad(dyb, c["a_s"], gm["D_fc2.weight"])
+    big_later: list = []
+    if _DETACH_BIG:
+        a_s_, dms2_, xn_ = c["a_s"], c["dms2"], c["xn"]
+        big_later.append(lambda: ops.colsum(dyb, gm["D_fc2.bias"], at=dms2_, ntok=N))
+        big_later.append(lambda: ops.wgrad(dyb, a_s_, gm["D_fc2.weight"]))
+    else:
+        ops.colsum(dyb, gm["D_fc2.bias"], at=c["dms2"], ntok=N)
+        ops.wgrad(dyb, c["a_s"], gm["D_fc2.weight"])
     dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
     ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=c["hcat_pre"], act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
              at=c["dms2"], ntok=N)
-    ops.wgrad(dcat[:, H4:], c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
+    if _DETACH_BIG:
+        dcat_ = dcat
+        big_later.append(lambda: ops.wgrad(dcat_[:, H4:], xn_, gm["D_fc1.weight"], gm["D_fc1.bias"]))
+    else:
+        ops.wgrad(dcat[:, H4:], c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
     dxn = _empty((M, D), BF16, dev)
     ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
     del dcat
@@ -413,7 +424,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     del dxn
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
-    later: list = []       # the class-token adapters' weight gradients: nobody downstream waits for them
+    later: list = big_later       # the adapters' weight gradients: nobody downstream waits for them
     with _Fork(dev) as fork:
         dsv = _empty((BT, D), F32, dev)
         ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
