@@ -182,6 +182,7 @@ _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
+_EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
 _RESERVE_CUS = int(os.environ.get("AIM_RESERVE_CUS", "0"))      # CUs the persistent GEMMs leave free inside a fork
 
 
@@ -269,6 +270,25 @@ class _Fork:
                 f()
         keep.extend(calls)
 
+    def run_beside(self, fn):
+        """Run ``fn`` on the third stream, ordered after the main stream's work so far; returns the event that marks
+        its completion (None when streams are off: ``fn`` then ran inline)."""
+        if not self.enabled:
+            fn()
+            return None
+        key = (self.dev.type, self.dev.index)
+        if key not in _DETACHED:
+            _DETACHED[key] = torch.cuda.Stream(device=self.dev)
+        w = _DETACHED[key]
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        w.wait_event(ev)
+        with torch.cuda.stream(w):
+            fn()
+        done = torch.cuda.Event()
+        done.record(w)
+        return done
+
     @staticmethod
     def join_detached(dev):
         """The current stream waits for everything queued by ``run_detached``."""
@@ -326,11 +346,17 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
         crs = _empty((BT, D), F32, dev)
         ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
-    # main stream: the ow statistic of lamda (:149-151), then the spatial attention (:264) -- independent of the class path
+    # the ow statistic of lamda (:149-151): a batched 197x197x768 GEMM, independent of the class-token path and of the
+    # spatial attention (:264) -- on the third stream beside both (AIM_EXPSUM_DETACHED=0: on the main stream, first)
     nt = ops.expsum_tiles(N, N)
     part = _empty((BT, nt, 2), F32, dev)
-    ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
-             stride_w=N * 3 * D, scale=0.125)
+
+    def expsum():
+        ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
+                 stride_w=N * 3 * D, scale=0.125)
+
+    part_ready = fork.run_beside(expsum) if _EXPSUM_DETACHED else expsum()
+
     def lamda_chain():
         # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
         lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
@@ -341,7 +367,10 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         return (lam, oml, sin) + _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, dev, out_f32=True)
 
     if _LAMBDA_ON_SIDE:               # the chain runs beside the spatial attention instead of after it
-        fork.sync_side_to_main()      # it needs `part`
+        if part_ready is not None:
+            fork.side_stream.wait_event(part_ready)      # it needs `part`
+        else:
+            fork.sync_side_to_main()
         with fork.side():
             lam, oml, sin, sv, s_pre, s_h = lamda_chain()
     ao = _empty((M, D), BF16, dev)
@@ -349,6 +378,8 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     ops.attn_fwd(qkv, ao, lse, BT, N, H)
     fork.join()
     if not _LAMBDA_ON_SIDE:
+        if part_ready is not None:
+            torch.cuda.current_stream(dev).wait_event(part_ready)
         lam, oml, sin, sv, s_pre, s_h = lamda_chain()
     # x1 = x + (1 - lamda) * out_proj(ao) + drop_path(scale * s_vec)
     x1 = _empty((M, D), F32, dev)
