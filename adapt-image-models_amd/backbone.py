@@ -177,9 +177,21 @@ def _empty(shape, dtype, dev):
 # attention kernels, which do not depend on it; the two are joined with events before `lamda`.
 _SIDE = {}
 _DETACHED = {}
+_JOIN_STATS = [] if os.environ.get("AIM_JOIN_STATS") else None     # (tag, event, event) per join
+
+
+def join_stats():
+    """ms the main stream spent waiting in _Fork.join(), per tag (AIM_JOIN_STATS=1; call after a device sync)."""
+    out = {}
+    for tag, e0, e1 in _JOIN_STATS or []:
+        out[tag] = out.get(tag, 0.0) + e0.elapsed_time(e1)
+    if _JOIN_STATS is not None:
+        _JOIN_STATS.clear()
+    return out
 _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
 _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
+_CLS_EARLY = os.environ.get("AIM_CLS_EARLY", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
@@ -193,9 +205,10 @@ class _Fork:
     the section is entered (the first section) or when ``f.sync_side_to_main()`` was last called.  ``f.join()``
     makes the main stream wait for all sections.  With ``AIM_SIDE_STREAM=0`` every section simply runs inline."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, tag: str = ""):
         self.enabled = _USE_SIDE
         self.dev = dev
+        self.tag = tag
         self.started = False
         if self.enabled:
             key = (dev.type, dev.index)
@@ -304,6 +317,13 @@ class _Fork:
                 ops.gemm_reserve_cus(0)
             done = torch.cuda.Event()
             done.record(self.side_stream)
+            if _JOIN_STATS is not None:      # diagnostics: how long the main stream sits in this wait
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.main)
+                self.main.wait_event(done)
+                e1.record(self.main)
+                _JOIN_STATS.append((self.tag, e0, e1))
+                return
             self.main.wait_event(done)
 
 
@@ -325,19 +345,15 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     M, D = x.shape
     BT = B * T
     r = fz.r
-    # ln_1 (once) + fused QKV projection
-    xl = _empty((M, D), BF16, dev)
-    mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
-    ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
-    qkv = _empty((M, 3 * D), BF16, dev)
-    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
-    del xl
-    # temporal attention over the class tokens + T_Adapter (vit_clip.py:220-229), then the cross term;
-    # on the side stream, concurrent with the spatial attention below
-    with _Fork(dev) as fork:
+    # Class-token path on the side stream: temporal attention over the class tokens + T_Adapter (vit_clip.py:220-229),
+    # then the cross term.  It needs q/k/v of the B*T class rows only, so those are projected apart (ln_1 + QKV on
+    # 512 rows) and the chain starts beside the big ln_1 / QKV GEMM instead of after them (AIM_CLS_EARLY=0: after).
+    fork = _Fork(dev, "fwd")
+
+    def cls_chain(qkv_src, n_stride):
         ot = _empty((BT, D), BF16, dev)
         probs = _empty((B, H, T, T), F32, dev)
-        ops.cls_attn_fwd(qkv, ot, probs, B, T, N, H)
+        ops.cls_attn_fwd(qkv_src, ot, probs, B, T, n_stride, H)
         ta = _empty((BT, D), BF16, dev)
         ops.gemm(ot, fz.Wo, ops.EPI_BF16, ta, bias=fz.bo)
         xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, dev, out_f32=False)
@@ -346,6 +362,26 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
         crs = _empty((BT, D), F32, dev)
         ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
+        return probs, ta, t_pre, t_h, kv, crs
+
+    if _CLS_EARLY:
+        with fork.side():
+            xl_cls = _empty((BT, D), BF16, dev)
+            ops.layernorm_fwd(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls, mean=_empty((BT,), F32, dev),
+                              rstd=_empty((BT,), F32, dev))
+            qkv_cls = _empty((BT, 3 * D), BF16, dev)
+            ops.gemm(xl_cls, fz.Wqkv, ops.EPI_BF16, qkv_cls, bias=fz.bqkv)
+            probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv_cls, 1)      # "N = 1": the rows ARE the class tokens
+    # main stream: ln_1 (once) + fused QKV projection
+    xl = _empty((M, D), BF16, dev)
+    mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
+    ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
+    qkv = _empty((M, 3 * D), BF16, dev)
+    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
+    del xl
+    if not _CLS_EARLY:
+        with fork.side():
+            probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv, N)
     # the ow statistic of lamda (:149-151): a batched 197x197x768 GEMM, independent of the class-token path and of the
     # spatial attention (:264) -- on the third stream beside both (AIM_EXPSUM_DETACHED=0: on the main stream, first)
     nt = ops.expsum_tiles(N, N)
@@ -456,7 +492,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
     later: list = big_later       # the adapters' weight gradients: nobody downstream waits for them
-    with _Fork(dev) as fork:
+    with _Fork(dev, "bwd") as fork:
         dsv = _empty((BT, D), F32, dev)
         ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
         # S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo

@@ -145,6 +145,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_val = float(losses["loss_cls"].detach())
+    if os.environ.get("AIM_JOIN_STATS") and rank == 0:
+        from aim_amd import backbone as _bb
+        print("join stalls, ms per step:", {k: round(v / (args.steps + args.warmup), 3) for k, v in _bb.join_stats().items()}, file=sys.stderr)
 
     if rank == 0:
         clips = B * world * args.steps
