@@ -9,6 +9,7 @@
 //        of 16-key tiles:  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta) / 8 and
 //        dQ^T += K^T dS^T with the dS^T accumulators used directly as the MFMA's second operand
 //        (K^T fragments by ds_read_b64_tr_b16).  Also writes delta = rowsum(dO o O).
+//        (Prefetching the K / V row fragments one key pair ahead was measured: 128 VGPRs + spill, 6 % slower.)
 //   dkv: key on the MFMA lane.  A wave owns 32 keys (K/V fragments in registers) and sweeps the
 //        queries 32 at a time:  S = Q K^T,  dP = dO V^T,  then  dV^T += dO^T P  and  dK^T += Q^T dS
 //        with P / dS accumulators as the second operand and Q^T / dO^T fragments by transposing
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv, int N, int H, int nq32) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -176,58 +177,75 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 dk[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dv[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        for (int qs = 0; qs < nq32 / 32; ++qs) {
+        // LDS operands of a 32-query step: row fragments + (L, delta) for S / dP, transposed fragments for dV / dK.
+        // The transposed fragments of step qs are requested at the TOP of the step (they are used in its second half) and
+        // the row fragments of step qs+1 in its MIDDLE, into the registers the S / dP MFMAs have just released: with
+        // 2 waves per SIMD nobody else hides an LDS round trip per MFMA group.
+        struct RowSet {
+            bf16x8 qa[2][2], oa[2][2];
+            float Lr[2][4], Dr[2][4];
+        };
+        auto load_rows = [&](int qs, RowSet& rs) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int qrow = (2 * qs + w) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    rs.qa[w][ks] = lds_read8(sQ + swz_off(qrow + frow, ks * 4 + fq));
+                    rs.oa[w][ks] = lds_read8(sO + swz_off(qrow + frow, ks * 4 + fq));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rs.Lr[w][e] = sL[qrow + fq * 4 + e];
+                    rs.Dr[w][e] = sD[qrow + fq * 4 + e];
+                }
+            }
+        };
+        auto step = [&](int qs, RowSet& cur, bool more) {
+            bf16x4 ta[4], tb[4], tc[4], td[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int r0 = qs * 32 + fq * 4 + (frow >> 2);
+                const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                ta[dt] = lds_read_tr4(sQ + swz_off(r0, ch) + half);
+                tb[dt] = lds_read_tr4(sQ + swz_off(r0 + 16, ch) + half);
+                tc[dt] = lds_read_tr4(sO + swz_off(r0, ch) + half);
+                td[dt] = lds_read_tr4(sO + swz_off(r0 + 16, ch) + half);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the requests up here: the scheduler would sink them to their uses
             bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int w = 0; w < 2; ++w) {  // the two 16-query tiles of this step
-                const int qrow = (2 * qs + w) * 16;
-                bf16x8 qa[2], oa[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    qa[ks] = lds_read8(sQ + swz_off(qrow + frow, ks * 4 + fq));
-                    oa[ks] = lds_read8(sO + swz_off(qrow + frow, ks * 4 + fq));
-                }
-                float Lr[4], Dr[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Lr[e] = sL[qrow + fq * 4 + e];
-                    Dr[e] = sD[qrow + fq * 4 + e];
-                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[u][ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[ks], vf[u][ks], dp, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.qa[w][ks], kf[u][ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.oa[w][ks], vf[u][ks], dp, 0, 0, 0);
                     }
                     // No masks: a key past N is a clamped duplicate whose dK / dV rows are never stored; a query past N
                     // has zero-filled Q and dO rows (and L = delta = 0), so it adds nothing to dK or dV.
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(s[e] * C2 - Lr[e]);
+                        const float p = __builtin_amdgcn_exp2f(s[e] * C2 - cur.Lr[w][e]);
                         pf[u][w * 4 + e] = (bf16_t)p;
-                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - Dr[e]));
+                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - cur.Dr[w][e]));
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_rows(qs + 1, cur);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int r0 = qs * 32 + fq * 4 + (frow >> 2);
-                const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
                 bf16x8 qt8, ot8;
-                {
-                    const bf16x4 a = lds_read_tr4(sQ + swz_off(r0, ch) + half);
-                    const bf16x4 b = lds_read_tr4(sQ + swz_off(r0 + 16, ch) + half);
-                    const bf16x4 c = lds_read_tr4(sO + swz_off(r0, ch) + half);
-                    const bf16x4 d = lds_read_tr4(sO + swz_off(r0 + 16, ch) + half);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        qt8[e] = a[e];
-                        qt8[4 + e] = b[e];
-                        ot8[e] = c[e];
-                        ot8[4 + e] = d[e];
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    qt8[e] = ta[dt][e];
+                    qt8[4 + e] = tb[dt][e];
+                    ot8[e] = tc[dt][e];
+                    ot8[4 + e] = td[dt][e];
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -235,6 +253,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                     dk[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsf[u], dk[dt][u], 0, 0, 0);
                 }
             }
+        };
+        {
+            const int nsteps = nq32 / 32;
+            RowSet rows;
+            load_rows(0, rows);
+            for (int qs = 0; qs < nsteps; ++qs) step(qs, rows, qs + 1 < nsteps);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
