@@ -291,16 +291,31 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rs * v[e]);
                 } else if constexpr (EPI == EPI_ACT) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pre[e] = (bf16_t)v[e];
-                        const float x = (float)pre[e];
-                        o[e] = (bf16_t)(rs * (act == ACT_QGELU ? quick_gelu(x) : gelu_erf(x)));
+                    for (int e = 0; e < 8; ++e) pre[e] = (bf16_t)v[e];
+                    if (act == ACT_QGELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 y = quick_gelu2(f32x2{(float)pre[e], (float)pre[e + 1]}) * rs;
+                            o[e] = (bf16_t)y[0];
+                            o[e + 1] = (bf16_t)y[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rs * gelu_erf((float)pre[e]));
                     }
                 } else {
+                    if (act == ACT_QGELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (float)ax[sp][e];
-                        o[e] = (bf16_t)(rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(x) : gelu_erf_grad(x)));
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 d = quick_gelu_grad2(f32x2{(float)ax[sp][e], (float)ax[sp][e + 1]});
+                            const f32x2 y = (f32x2{v[e], v[e + 1]} * rs) * d;
+                            o[e] = (bf16_t)y[0];
+                            o[e + 1] = (bf16_t)y[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            o[e] = (bf16_t)(rs * v[e] * gelu_erf_grad((float)ax[sp][e]));
                     }
                 }
                 buf_store16(rOut, voO, o);

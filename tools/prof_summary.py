@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""rocprofv3 results database -> markdown summary (per-kernel table, per-stream busy time).
+
+usage: prof_summary.py <run_results.db> <steps-in-trace> [title]
+The database comes from  rocprofv3 --kernel-trace --stats -d DIR -o run -- python3 bench.py ...  (kernel dispatch table)."""
+import collections
+import re
+import sqlite3
+import sys
+
+
+def main():
+    db, steps = sys.argv[1], int(sys.argv[2])
+    title = sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 --kernel-trace --stats"
+    cur = sqlite3.connect(db).cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "kernel_symbol" in t][0]
+    rows = list(cur.execute(f"select d.stream_id, d.start, d.end, s.display_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+
+    def short(n):
+        n = re.sub(r"\(anonymous namespace\)::|void ", "", n)
+        n = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", n)
+        return n[:72]
+
+    busy = collections.defaultdict(float)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for st, a, b, n in rows:
+        busy[st] += (b - a) / 1e6
+        agg[short(n)][0] += 1
+        agg[short(n)][1] += (b - a) / 1e6
+    tot = sum(v[1] for v in agg.values())
+    print(f"# {title}\n")
+    print(f"{len(rows)} kernel dispatches over {steps} steps; kernel-time sum {tot / steps:.2f} ms/step "
+          f"(streams overlap, so the sum exceeds wall time).\n")
+    print("Busy time per HIP stream (ms/step): " + ", ".join(f"stream {k}: {v / steps:.2f}" for k, v in sorted(busy.items())) + "\n")
+    print("| kernel | calls/step | ms/step | avg us | % of kernel time |\n|---|---|---|---|---|")
+    for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+        print(f"| `{n}` | {v[0] / steps:.1f} | {v[1] / steps:.3f} | {v[1] / v[0] * 1e3:.1f} | {100 * v[1] / tot:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
