@@ -382,8 +382,15 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     if not _CLS_EARLY:
         with fork.side():
             probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv, N)
-    # the ow statistic of lamda (:149-151): a batched 197x197x768 GEMM, independent of the class-token path and of the
-    # spatial attention (:264) -- on the third stream beside both (AIM_EXPSUM_DETACHED=0: on the main stream, first)
+    # lamda's cross scores q_i . kx (one pass over q) go to the side stream as soon as q exists ...
+    ss = None
+    if _LAMBDA_ON_SIDE and _CLS_EARLY:
+        fork.sync_side_to_main()
+        with fork.side():
+            ss = _empty((BT, N), F32, dev)
+            ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
+    # ... beside the ow statistic of lamda (:149-151): a batched 197x197x768 GEMM, independent of the class-token path
+    # and of the spatial attention (:264)
     nt = ops.expsum_tiles(N, N)
     part = _empty((BT, nt, 2), F32, dev)
 
@@ -396,7 +403,7 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     def lamda_chain():
         # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
         lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
-        ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125)
+        ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125, ss=ss)
         # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
         sin = _empty((BT, D), BF16, dev)
         ops.scale_rows(crs, lam, y=sin)

@@ -115,26 +115,52 @@ __global__ __launch_bounds__(64) void cls_attn_bwd_kernel(const bf16_t* __restri
     }
 }
 
-// one block (4 waves) per frame
-__global__ __launch_bounds__(256) void lambda_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx,
-                                                     int ldkx, const float* __restrict__ partials, int ntiles,
-                                                     float* __restrict__ lam, float* __restrict__ oml, int N, int D,
-                                                     float scale) {
-    __shared__ float ss[320];
-    __shared__ float red[8];
+// ss[bt][i] = scale * q_i . kx[bt] over the full width D: the memory-bound half of lamda's cw statistic (one pass over q).
+// Split from lambda_kernel so that it runs as soon as q exists, beside the ow GEMM, instead of after it.
+__global__ __launch_bounds__(256) void qk_cross_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx, int ldkx,
+                                                       float* __restrict__ ssg, int N, int D, float scale) {
     const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = 3 * D;
     const bf16_t* kr = kx + (long long)bt * ldkx;
     for (int i = wave; i < N; i += 4) {
         const bf16_t* qr = qkv + ((long long)bt * N + i) * ld;
         float acc = 0.f;
-        for (int c = lane * 4; c < D; c += 256) {
-            const bf16x4 a = *(const bf16x4*)(qr + c);
-            const bf16x4 b = *(const bf16x4*)(kr + c);
-            acc += (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1] + (float)a[2] * (float)b[2] + (float)a[3] * (float)b[3];
+        for (int c = lane * 8; c < D; c += 512) {
+            const bf16x8 a = *(const bf16x8*)(qr + c);
+            const bf16x8 b = *(const bf16x8*)(kr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
         }
         acc = wave_sum(acc);
-        if (lane == 0) ss[i] = acc * scale;
+        if (lane == 0) ssg[(long long)bt * N + i] = acc * scale;
+    }
+}
+
+// one block (4 waves) per frame; ssg == nullptr: compute the cross scores here (one-call form)
+__global__ __launch_bounds__(256) void lambda_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx,
+                                                     int ldkx, const float* __restrict__ ssg,
+                                                     const float* __restrict__ partials, int ntiles,
+                                                     float* __restrict__ lam, float* __restrict__ oml, int N, int D,
+                                                     float scale) {
+    __shared__ float ss[320];
+    __shared__ float red[8];
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = 3 * D;
+    if (ssg) {
+        for (int i = tid; i < N; i += 256) ss[i] = ssg[(long long)bt * N + i];
+    } else {
+        const bf16_t* kr = kx + (long long)bt * ldkx;
+        for (int i = wave; i < N; i += 4) {
+            const bf16_t* qr = qkv + ((long long)bt * N + i) * ld;
+            float acc = 0.f;
+            for (int c = lane * 4; c < D; c += 256) {
+                const bf16x4 a = *(const bf16x4*)(qr + c);
+                const bf16x4 b = *(const bf16x4*)(kr + c);
+                acc += (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1] + (float)a[2] * (float)b[2] + (float)a[3] * (float)b[3];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) ss[i] = acc * scale;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -188,12 +214,23 @@ extern "C" int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const a
     return 0;
 }
 
-extern "C" int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* partials, int ntiles, float* lam,
-                          float* one_minus_lam, int BT, int N, int D, float scale, void* stream) {
+extern "C" int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, int BT, int N, int D, float scale,
+                            void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 0 && D > 0 && (D % 8) == 0 && ldkx >= D && (ldkx % 8) == 0, "qk_cross: unsupported shape BT=%d N=%d D=%d", BT, N, D);
+    AIM_CHECK_ARG(qkv && kx && ss, "qk_cross: null pointer");
+    hipLaunchKernelGGL(qk_cross_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)kx,
+                       ldkx, ss, N, D, scale);
+    AIM_CHECK_LAUNCH("aim_qk_cross");
+    return 0;
+}
+
+extern "C" int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* ss, const float* partials,
+                          int ntiles, float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream) {
     AIM_CHECK_ARG(BT > 0 && N > 0 && N <= 320 && D > 0 && (D % 4) == 0, "lambda: unsupported shape BT=%d N=%d D=%d", BT, N, D);
-    AIM_CHECK_ARG(qkv && kx && partials && lam && ntiles > 0 && ldkx >= D && (ldkx % 4) == 0, "lambda: bad arguments");
+    AIM_CHECK_ARG(partials && lam && ntiles > 0, "lambda: bad arguments");
+    AIM_CHECK_ARG(ss || (qkv && kx && ldkx >= D && (ldkx % 4) == 0), "lambda: needs either the cross scores or q and kx");
     hipLaunchKernelGGL(lambda_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv,
-                       (const bf16_t*)kx, ldkx, partials, ntiles, lam, one_minus_lam, N, D, scale);
+                       (const bf16_t*)kx, ldkx, ss, partials, ntiles, lam, one_minus_lam, N, D, scale);
     AIM_CHECK_LAUNCH("aim_lambda");
     return 0;
 }

@@ -185,11 +185,19 @@ def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H, compact: bool = False):
                                           int(compact), B, T, N, H, _stream()), "aim_cls_attn_bwd")
 
 
-def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale):
+def qk_cross(qkv, kx, ss, BT, N, D, scale):
+    """ss[bt, i] = scale * q_i . kx[bt] (full width D): the pass over q of lamda's cw statistic."""
+    _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(ss, F32, "ss")
+    check(load_library().aim_qk_cross(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), ss.data_ptr(), BT, N, D, scale,
+                                      _stream()), "aim_qk_cross")
+
+
+def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale, ss=None):
+    """lamda = cw / (cw + ow); ``ss`` = precomputed cross scores (qk_cross), else computed here from q and kx."""
     _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(partials, F32, "partials"); _chk(lam, F32, "lam")
-    _chk(one_minus, F32, "one_minus")
-    check(load_library().aim_lambda(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), partials.data_ptr(), ntiles, lam.data_ptr(),
-                                    _p(one_minus), BT, N, D, scale, _stream()), "aim_lambda")
+    _chk(one_minus, F32, "one_minus"); _chk(ss, F32, "ss")
+    check(load_library().aim_lambda(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), _p(ss), partials.data_ptr(), ntiles,
+                                    lam.data_ptr(), _p(one_minus), BT, N, D, scale, _stream()), "aim_lambda")
 
 
 _IN_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.bfloat16: 2}

@@ -150,7 +150,10 @@ int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* do
  *            partials [BT, ntiles, 2];  cw[bt] = sum_i exp(q_i . kx[bt] / 8) is computed here.
  *   Both sums share one max shift (identical ratio, no overflow).  lam [BT] f32; one_minus [BT].
  * ------------------------------------------------------------------------------------------ */
-int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* partials, int ntiles,
+/* ss [BT, N] f32 = scale * q_i . kx[bt] (full width): the one pass over q that lamda's cw needs; aim_lambda accepts it so
+ * that this pass can run as soon as q exists.  ss == NULL in aim_lambda: computed inside (one-call form). */
+int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, int BT, int N, int D, float scale, void* stream);
+int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* ss, const float* partials, int ntiles,
                float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -256,6 +256,12 @@ def test_lambda():
              scale=0.125)
     lam, oml = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
     ops.lambda_(qkv, kx, part, nt, lam, oml, BT, N, D, 0.125)
+    # two-call form: the cross scores computed apart
+    ss = torch.zeros((BT, N), device=DEV)
+    ops.qk_cross(qkv, kx, ss, BT, N, D, 0.125)
+    lam2, oml2 = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
+    ops.lambda_(qkv, kx, part, nt, lam2, oml2, BT, N, D, 0.125, ss=ss)
+    close(lam2, lam, 1e-5, 1e-6, "lamda (two-call form)")
     qf, kf = q.float().reshape(BT, N, D).double(), k.float().reshape(BT, N, D).double()
     ow = torch.exp(qf @ kf.transpose(1, 2) * 0.125).sum((1, 2))
     cw = torch.exp((qf @ kx.double().unsqueeze(-1)).squeeze(-1) * 0.125).sum(1)
