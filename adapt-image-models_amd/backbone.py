@@ -192,6 +192,7 @@ _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
 _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
 _CLS_EARLY = os.environ.get("AIM_CLS_EARLY", "1") != "0"
+_LAMBDA_FUSED = os.environ.get("AIM_LAMBDA_FUSED", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
@@ -217,6 +218,13 @@ class _Fork:
                 _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AIM_SIDE_PRIORITY", "-1")))
             self.side_stream = _SIDE[key]
             self.main = torch.cuda.current_stream(dev)
+
+    def sync_main_to_side(self):
+        """The main stream waits for everything queued on the side stream so far."""
+        if self.enabled and self.started:
+            ev = torch.cuda.Event()
+            ev.record(self.side_stream)
+            self.main.wait_event(ev)
 
     def sync_side_to_main(self):
         """The side stream waits for everything queued on the main stream so far."""
@@ -382,28 +390,39 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     if not _CLS_EARLY:
         with fork.side():
             probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv, N)
-    # lamda's cross scores q_i . kx (one pass over q) go to the side stream as soon as q exists ...
-    ss = None
-    if _LAMBDA_ON_SIDE and _CLS_EARLY:
-        fork.sync_side_to_main()
-        with fork.side():
-            ss = _empty((BT, N), F32, dev)
-            ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
-    # ... beside the ow statistic of lamda (:149-151): a batched 197x197x768 GEMM, independent of the class-token path
-    # and of the spatial attention (:264)
-    nt = ops.expsum_tiles(N, N)
-    part = _empty((BT, nt, 2), F32, dev)
-
-    def expsum():
+    # lamda = cw / (cw + ow)  (:149-151,184-186,272; no grad): `ow` is a batched 197x197x768 GEMM reduced to (max, sum exp)
+    # partials, independent of the class-token path and of the spatial attention (:264).  Fused form: kx, ready early on
+    # the side stream, rides that GEMM as a 198th key, so `cw` comes out of the same launch (no separate pass over q).
+    fused = _LAMBDA_FUSED and _CLS_EARLY and N < 256 and ops.expsum_tiles(N, N) == 8
+    ss, part_ready = None, None
+    if fused:
+        fork.sync_main_to_side()          # kx
+        nt = 16
+        part = _empty((BT, nt, 2), F32, dev)
         ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
-                 stride_w=N * 3 * D, scale=0.125)
+                 stride_w=N * 3 * D, scale=0.125, xrow=kv)
+    else:
+        # the cross scores q_i . kx (one pass over q) go to the side stream as soon as q exists, beside the ow GEMM
+        if _LAMBDA_ON_SIDE and _CLS_EARLY:
+            fork.sync_side_to_main()
+            with fork.side():
+                ss = _empty((BT, N), F32, dev)
+                ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
+        nt = ops.expsum_tiles(N, N)
+        part = _empty((BT, nt, 2), F32, dev)
 
-    part_ready = fork.run_beside(expsum) if _EXPSUM_DETACHED else expsum()
+        def expsum():
+            ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
+                     stride_w=N * 3 * D, scale=0.125)
+
+        part_ready = fork.run_beside(expsum) if _EXPSUM_DETACHED else expsum()
 
     def lamda_chain():
-        # lamda = cw / (cw + ow)  (:149-151,184-186,272) -- no grad
         lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
-        ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125, ss=ss)
+        if fused:
+            ops.lambda_partials(part, lam, oml, BT)
+        else:
+            ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125, ss=ss)
         # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
         sin = _empty((BT, D), BF16, dev)
         ops.scale_rows(crs, lam, y=sin)

@@ -22,4 +22,6 @@ extern "C" int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch,
     return aim_gemm_launch(*args, epilogue, batch, (hipStream_t)stream);
 }
 
-extern "C" int aim_gemm_expsum_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 127) / 128); }
+extern "C" int aim_gemm_expsum_tiles(int M, int N) {
+    return aim_expsum_use256(M, N) ? 8 : ((M + 127) / 128) * ((N + 127) / 128);
+}

@@ -214,6 +214,31 @@ extern "C" int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const a
     return 0;
 }
 
+// one thread per frame: 8 ow partials + 8 cw partials -> lamda
+__global__ void lambda_partials_kernel(const float* __restrict__ part, float* __restrict__ lam, float* __restrict__ oml, int BT) {
+    const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt >= BT) return;
+    const float* p = part + (long long)bt * 32;
+    float mx = -INFINITY;
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, p[2 * t]);
+    float o = 0.f, c = 0.f;
+    for (int t = 0; t < 8; ++t)
+        if (p[2 * t] > -INFINITY) o += p[2 * t + 1] * expf(p[2 * t] - mx);
+    for (int t = 8; t < 16; ++t)
+        if (p[2 * t] > -INFINITY) c += p[2 * t + 1] * expf(p[2 * t] - mx);
+    const float l = c / (c + o);
+    lam[bt] = l;
+    if (oml) oml[bt] = 1.0f - l;
+}
+
+extern "C" int aim_lambda_partials(const float* partials, float* lam, float* one_minus_lam, int BT, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && partials && lam, "lambda_partials: bad arguments");
+    hipLaunchKernelGGL(lambda_partials_kernel, dim3((BT + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, lam,
+                       one_minus_lam, BT);
+    AIM_CHECK_LAUNCH("aim_lambda_partials");
+    return 0;
+}
+
 extern "C" int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, int BT, int N, int D, float scale,
                             void* stream) {
     AIM_CHECK_ARG(BT > 0 && N > 0 && D > 0 && (D % 8) == 0 && ldkx >= D && (ldkx % 8) == 0, "qk_cross: unsupported shape BT=%d N=%d D=%d", BT, N, D);

@@ -185,7 +185,12 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
                                          : ((g.ldo % 8) == 0 && (epi != EPI_ACT || (g.ldo2 % 8) == 0) &&
                                             (epi != EPI_DACT || (g.ldaux % 8) == 0)));
     if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64 && wide_ok)
-        return aim_gemm256_launch(g, epi, st);
+        return aim_gemm256_launch(g, epi, 1, st);
+    if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N)) {
+        AIM_CHECK_ARG(!g.xrow || (g.N < 256 && (g.ldx % 8) == 0), "gemm: EXPSUM extra key needs N < 256 and ldx %% 8 == 0");
+        return aim_gemm256_launch(g, epi, batch, st);
+    }
+    AIM_CHECK_ARG(!g.xrow, "gemm: `xrow` is only supported by the one-tile-per-item EXPSUM path");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(g, batch, st);
         case EPI_ACT:

@@ -46,23 +46,27 @@ constexpr int LDS_BYTES = 2 * BUF + 8 * EPI_SCRATCH;   // K-loop images + 8 wave
 
 // Per-tile staging state: buffer descriptors of the tile's A rows / W rows and the per-lane row offsets.
 struct TileSrc {
-    __amdgpu_buffer_rsrc_t rA, rW;
+    __amdgpu_buffer_rsrc_t rA, rW, rX;      // rX: the item's extra W row (EXPSUM `xrow`), else empty
     unsigned voA[2][2], voW[2][2];   // [half][piece]; AIM_OOB for rows past M / N
-    int m0, n0;
+    int m0, n0, z;
 };
 
-__device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int ntiles, int tiles_n, int wave, int srow,
-                                             int schunk) {
+// A batched problem (strideA / strideW between items) is walked as extra row tiles: virtual row tile tmv = z * tiles_m1 + tm.
+__device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int ntiles, int tiles_n, int tiles_m1, int wave,
+                                             int srow, int schunk) {
     TileSrc t;
     const bool live = tile < ntiles;
-    const int tn = live ? tile % tiles_n : 0, tm = live ? tile / tiles_n : 0;
+    const int tn = live ? tile % tiles_n : 0, tmv = live ? tile / tiles_n : 0;
+    const int z = tmv / tiles_m1, tm = tmv - z * tiles_m1;
+    t.z = z;
     t.m0 = tm * 256;
     t.n0 = tn * 256;
     const int rowsA = live ? g.M - t.m0 : 0, rowsW = live ? g.N - t.n0 : 0;
-    const bf16_t* Ab = (const bf16_t*)g.A + (long long)t.m0 * g.lda;
-    const bf16_t* Wb = (const bf16_t*)g.W + (long long)t.n0 * g.ldw;
+    const bf16_t* Ab = (const bf16_t*)g.A + (long long)z * g.strideA + (long long)t.m0 * g.lda;
+    const bf16_t* Wb = (const bf16_t*)g.W + (long long)z * g.strideW + (long long)t.n0 * g.ldw;
     t.rA = make_rsrc(Ab, live ? ((long long)(rowsA - 1) * g.lda + g.K) * 2 : 0);
     t.rW = make_rsrc(Wb, live ? ((long long)(rowsW - 1) * g.ldw + g.K) * 2 : 0);
+    t.rX = make_rsrc(g.xrow ? (const bf16_t*)g.xrow + (long long)z * g.ldx : nullptr, (live && g.xrow) ? (long long)g.K * 2 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -79,7 +83,7 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
 // the schedule's look-ahead (up to 3 K-tiles) simply runs into the NEXT tile's first K-tiles, so its
 // prologue latency is hidden behind this tile's last MFMAs and its epilogue.
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int ngroups, int phase_skew,
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int nbatch, int ngroups, int phase_skew,
                                                       unsigned long long* probe, int probe_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
@@ -92,6 +96,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int frow = lane & 15, fq = lane >> 4;
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
     const int nk = (g.K + 63) >> 6;
+    // EXPSUM with an extra key: the wave whose W pieces hold tile row g.N issues one more LDS-DMA per W stage pair,
+    // so its counted waits leave 5, not 4, operations in flight
+    const bool xw = EPI == EPI_EXPSUM && g.xrow != nullptr && wave == ((g.N & 127) >> 4);
     const int nkp = (nk + 1) & ~1;               // K-slots per tile (even)
 
     // ---- tile schedule: column groups per XCD ---------------------------------------------------
@@ -111,12 +118,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int ncols = min(cpg, tiles_n - c0);                     // may be <= 0 for a trailing empty group
     const int rank = (xcd / ng) * per_xcd + in_xcd;               // XCD-major inside the group
     const int wg_per_group = grouped ? (8 / ng) * per_xcd : (int)gridDim.x;
-    const int tiles_m = (g.M + 255) >> 8;
+    const int tiles_m1 = (g.M + 255) >> 8;
+    const int tiles_m = tiles_m1 * nbatch;
     const int nseq = ncols > 0 ? tiles_m * ncols : 0;
     auto seq_tile = [&](int seq) { return seq < nseq ? (seq / ncols) * tiles_n + c0 + seq % ncols : ntiles; };
     int seq = rank;
-    TileSrc cur = make_tile(g, seq_tile(seq), ntiles, tiles_n, wave, srow, schunk);
-    TileSrc nxt = make_tile(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, wave, srow, schunk);
+    TileSrc cur = make_tile(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+    TileSrc nxt = make_tile(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
 
     // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
     auto stage = [&](int buf, int which, int slot) {
@@ -139,6 +147,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
                 const unsigned vo = in_next ? nxt.voW[h][j] : cur.voW[h][j];
                 const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * 2) : AIM_OOB;
                 stage_piece(in_next ? nxt.rW : cur.rW, dst + j * 1024, v);
+                if constexpr (EPI == EPI_EXPSUM) {
+                    // the extra key: tile-local W row g.N comes from `xrow`.  Only the 8 lanes of that row take part
+                    // (EXEC-masked LDS-DMA writes only its active lanes' 16-byte slots), over the zero the piece above
+                    // left there; the wave that owns the row has ONE more vector-memory op per W stage (xw below).
+                    if (g.xrow && h * 128 + (wave * 2 + j) * 8 + srow == g.N)
+                        stage_piece(in_next ? nxt.rX : cur.rX, dst + j * 1024, kin ? (unsigned)((schunk * 8 + k0) * 2) : AIM_OOB);
+                }
             }
         }
     };
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 // sees them.  hipcc still flushes `vmcnt(0)` at the K-loop header while LDS-DMA is in flight (it is gone only when the
 // stage calls are compiled out); stamped, that costs ~40 of an iteration's ~5500 cycles.
 #define AIM_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
-#define AIM_VM4() __builtin_amdgcn_s_waitcnt(0x0F74)
+#define AIM_VM4() do { if (xw) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F74); } while (0)
 
     // prologue (first tile only): K-tile 0 complete, three half-tiles of K-tile 1 in flight
     stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);
@@ -282,7 +297,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         // images, so the scratch is separate (wave-private, no barrier needed).
         if (phase_skew && wm == 0) AIM_BAR();
         if (probe) { tp1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
-        wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
+        if constexpr (EPI == EPI_EXPSUM)
+            wave_expsum(g, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, lane,
+                        (float*)g.out + ((long long)(cur.z * tiles_m1 + (cur.m0 >> 8)) * tiles_n + (cur.n0 >> 8)) *
+                                            (g.xrow ? 32 : 16) + wave * 2);
+        else
+            wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
         if (probe) {        // diagnostics (aim_gemm_probe): per-tile timestamps of wave 0, 100 MHz ticks
             const int slot = probe_i * (int)gridDim.x + (int)blockIdx.x;
             if (tid == 0 && slot < probe_cap) {
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
             ++probe_i;
         }
         cur = nxt;
-        nxt = make_tile(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, wave, srow, schunk);
+        nxt = make_tile(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }
@@ -304,13 +324,13 @@ int g_probe_cap = 0;
 int g_reserve_cus = 0;      // CUs the persistent grid leaves free (aim_gemm_reserve_cus)
 
 template <int EPI>
-int launch256(const GemmArgs& g, hipStream_t st) {
+int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256) * nbatch;
     // a persistent grid that fills every CU starves whatever runs beside it on another stream: the caller can keep a few
     // CUs out of the grid while such work is in flight
     const int cus = aim_num_cus() - g_reserve_cus > 8 ? aim_num_cus() - g_reserve_cus : 8;
@@ -326,7 +346,7 @@ int launch256(const GemmArgs& g, hipStream_t st) {
         grid = (grid / 8) * 8;     // XCD-aware schedule wants a multiple of 8; smaller grids use plain round-robin
     }
     static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, ngroups, phase_skew, g_probe, g_probe_cap);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew, g_probe, g_probe_cap);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }
@@ -346,13 +366,14 @@ extern "C" int aim_gemm_probe(void* buf, int capacity) {
     return 0;
 }
 
-int aim_gemm256_launch(const GemmArgs& g, int epi, hipStream_t st) {
+int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st) {
     AIM_CHECK_ARG((long long)256 * g.lda * 2 < 0x7fffffffLL && (long long)256 * g.ldw * 2 < 0x7fffffffLL, "gemm256: leading dimension too large");
     switch (epi) {
-        case EPI_BF16: return launch256<EPI_BF16>(g, st);
-        case EPI_ACT: return launch256<EPI_ACT>(g, st);
-        case EPI_DACT: return launch256<EPI_DACT>(g, st);
-        case EPI_F32: return launch256<EPI_F32>(g, st);
+        case EPI_BF16: return launch256<EPI_BF16>(g, nbatch, st);
+        case EPI_ACT: return launch256<EPI_ACT>(g, nbatch, st);
+        case EPI_DACT: return launch256<EPI_DACT>(g, nbatch, st);
+        case EPI_F32: return launch256<EPI_F32>(g, nbatch, st);
+        case EPI_EXPSUM: return launch256<EPI_EXPSUM>(g, nbatch, st);
     }
     aim_set_error("gemm256: unsupported epilogue %d", epi);
     return 1;

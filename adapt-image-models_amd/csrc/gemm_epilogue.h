@@ -403,3 +403,60 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         if (rowf) run4(std::true_type{}); else run4(std::false_type{});
     }
 }
+
+// EXPSUM for the 256x256 kernel: each wave emits ONE partial (max, sum exp(x - max)) over the valid elements of its
+// 128x64 sub-tile of scale * A W^T -> slot [wave] of the tile's 8 slots (aim_gemm_expsum_tiles counts them).  With an
+// extra key (g.xrow) column g.N is reduced apart into slot [8 + wave].
+__device__ __forceinline__ void wave_expsum(const GemmArgs& g, f32x4 (&acc)[8][4], int m_base, int n_base, int lane, float* slot) {
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool cross = g.xrow != nullptr;
+    float mx = -INFINITY, cmx = -INFINITY;
+    float cv[8];                       // this lane's scores against the extra key (at most one column, 8 rows)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m_base + i * 16 + frow;
+        cv[i] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[i][j][e] * g.scale;
+                if (cross && n + e == g.N && m < g.M) cv[i] = x;
+                const float v = (m < g.M && n + e < g.N) ? x : -INFINITY;
+                acc[i][j][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        cmx = fmaxf(cmx, cv[i]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+    if (mx > -INFINITY) {
+        const float m2 = mx * 1.4426950408889634f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f(acc[i][j][e] * 1.4426950408889634f - m2);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        slot[0] = mx;
+        slot[1] = s;
+    }
+    if (cross) {
+        cmx = wave_max(cmx);
+        float cs = 0.f;
+        if (cmx > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs += __builtin_amdgcn_exp2f((cv[i] - cmx) * 1.4426950408889634f);
+        }
+        cs = wave_sum(cs);
+        if (lane == 0) {
+            slot[16] = cmx;
+            slot[17] = cs;
+        }
+    }
+}

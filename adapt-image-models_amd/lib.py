@@ -28,6 +28,7 @@ class GemmArgs(Structure):
         ("aux", c_void_p), ("ldaux", c_int32),
         ("out", c_void_p), ("ldo", c_int32), ("out2", c_void_p), ("ldo2", c_int32),
         ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32), ("n_split", c_int32), ("act2", c_int32),
+        ("xrow", c_void_p), ("ldx", c_int32),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
     "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, I, P],
+    "aim_lambda_partials": [P, P, P, I, P],
     "aim_qk_cross": [P, P, I, P, I, I, I, F, P],
     "aim_lambda": [P, P, I, P, P, I, P, P, I, I, I, F, P],
     "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],

@@ -70,7 +70,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
          scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
          stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldv: Optional[int] = None, n_split: int = 0,
-         act2: int = 0):
+         act2: int = 0, xrow=None):
     """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
     lib = load_library()
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -98,6 +98,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     g.ldo2 = out2.stride(0) if out2 is not None else 0
     g.scale, g.act, g.rs_bias_only = scale, act, int(rs_bias_only)
     g.n_split, g.act2 = n_split, act2
+    _chk(xrow, BF16, "xrow")
+    g.xrow = _p(xrow)
+    g.ldx = xrow.stride(0) if xrow is not None else 0
     if epi in (EPI_BF16, EPI_ACT, EPI_DACT):
         _chk(out, BF16, "out")
     else:
@@ -183,6 +186,13 @@ def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H, compact: bool = False):
     _chk(qkv, BF16, "qkv"); _chk(dout_cls, BF16, "dout_cls"); _chk(dqkv, BF16, "dqkv"); _chk(probs, F32, "probs")
     check(load_library().aim_cls_attn_bwd(qkv.data_ptr(), probs.data_ptr(), dout_cls.data_ptr(), dqkv.data_ptr(),
                                           int(compact), B, T, N, H, _stream()), "aim_cls_attn_bwd")
+
+
+def lambda_partials(partials, lam, one_minus, BT):
+    """lamda from [BT, 16, 2] (max, sum) slots: 8 ``ow`` partials, 8 ``cw`` partials (EXPSUM GEMM with ``xrow``)."""
+    _chk(partials, F32, "partials"); _chk(lam, F32, "lam"); _chk(one_minus, F32, "one_minus")
+    check(load_library().aim_lambda_partials(partials.data_ptr(), lam.data_ptr(), _p(one_minus), BT, _stream()),
+          "aim_lambda_partials")
 
 
 def qk_cross(qkv, kx, ss, BT, N, D, scale):

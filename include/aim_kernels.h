@@ -79,6 +79,11 @@ typedef struct aim_gemm_args {
     /* column split for fused [frozen MLP | adapter] GEMMs (ACT / DACT): when n_split > 0, columns
        n < n_split use `act` with rs = 1, columns n >= n_split use `act2` with the row factor rs   */
     int32_t n_split, act2;
+    /* AIM_EPI_EXPSUM, one 256x256 tile per batch item (128 < max(M, N), N < 256) only: an EXTRA key.  Row N of W for batch
+       item z is xrow + z * ldx (K elements); the scores against it (column N of the tile) are reduced apart into slots
+       8..15 of the item's 16 (max, sum) slots -- lamda's `cw` rides along with its `ow` (vit_clip.py:149-151,184-186). */
+    const aim_bf16* xrow;
+    int32_t ldx;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
@@ -152,6 +157,8 @@ int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* do
  * ------------------------------------------------------------------------------------------ */
 /* ss [BT, N] f32 = scale * q_i . kx[bt] (full width): the one pass over q that lamda's cw needs; aim_lambda accepts it so
  * that this pass can run as soon as q exists.  ss == NULL in aim_lambda: computed inside (one-call form). */
+/* lamda from the 16 slots per frame of an AIM_EPI_EXPSUM launch with `xrow` (8 ow partials, 8 cw partials). */
+int aim_lambda_partials(const float* partials, float* lam, float* one_minus_lam, int BT, void* stream);
 int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, int BT, int N, int D, float scale, void* stream);
 int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* ss, const float* partials, int ntiles,
                float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream);

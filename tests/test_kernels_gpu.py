@@ -262,6 +262,14 @@ def test_lambda():
     lam2, oml2 = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
     ops.lambda_(qkv, kx, part, nt, lam2, oml2, BT, N, D, 0.125, ss=ss)
     close(lam2, lam, 1e-5, 1e-6, "lamda (two-call form)")
+    # fused form: kx rides the ow GEMM as an extra key (16 slots per frame: 8 ow + 8 cw)
+    part16 = torch.zeros((BT, 16, 2), device=DEV)
+    ops.gemm(q, k, ops.EPI_EXPSUM, part16, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D, stride_w=N * 3 * D, scale=0.125,
+             xrow=kx)
+    lam3, oml3 = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
+    ops.lambda_partials(part16, lam3, oml3, BT)
+    close(lam3, lam, 1e-4, 1e-6, "lamda (kx as an extra key of the ow GEMM)")
+    close(oml3, 1.0 - lam, 1e-4, 1e-6, "1 - lamda")
     qf, kf = q.float().reshape(BT, N, D).double(), k.float().reshape(BT, N, D).double()
     ow = torch.exp(qf @ kf.transpose(1, 2) * 0.125).sum((1, 2))
     cw = torch.exp((qf @ kx.double().unsqueeze(-1)).squeeze(-1) * 0.125).sum(1)
