@@ -224,6 +224,13 @@ class _Fork:
         if self.enabled and self.started:
             ev = torch.cuda.Event()
             ev.record(self.side_stream)
+            if _JOIN_STATS is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.main)
+                self.main.wait_event(ev)
+                e1.record(self.main)
+                _JOIN_STATS.append((self.tag + "-mid", e0, e1))
+                return
             self.main.wait_event(ev)
 
     def sync_side_to_main(self):

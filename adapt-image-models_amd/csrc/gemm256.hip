@@ -335,6 +335,16 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     // CUs out of the grid while such work is in flight
     const int cus = aim_num_cus() - g_reserve_cus > 8 ? aim_num_cus() - g_reserve_cus : 8;
     int grid = tiles < cus ? tiles : cus;
+    // balanced grid: the smallest multiple of 8 workgroups that still finishes in ceil(tiles / cus) rounds.  1 182 tiles take
+    // 5 rounds on 256 CUs and on 240: the 16 CUs that would idle through the last round are free for the other streams
+    // for the whole launch instead.
+    static const bool balanced = [] { const char* e = getenv("AIM_GEMM_BALANCED"); return !e || atoi(e) != 0; }();
+    if (balanced && tiles > cus) {
+        const int rounds = (tiles + cus - 1) / cus;
+        const int need = (tiles + rounds - 1) / rounds;
+        const int g8 = ((need + 7) / 8) * 8;
+        if (g8 < grid) grid = g8;
+    }
     // column groups: keep each group's weight slice (+ streaming A) inside an XCD's 4 MiB L2
     int ngroups = 1;
     static const int force_groups = [] { const char* e = getenv("AIM_GEMM_GROUPS"); return e ? atoi(e) : 0; }();
