@@ -324,7 +324,15 @@ class _Fork:
         if w is not None:
             ev = torch.cuda.Event()
             ev.record(w)
-            torch.cuda.current_stream(dev).wait_event(ev)
+            main = torch.cuda.current_stream(dev)
+            if _JOIN_STATS is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_event(ev)
+                e1.record(main)
+                _JOIN_STATS.append(("detached", e0, e1))
+                return
+            main.wait_event(ev)
 
     def join(self):
         if self.enabled and self.started:

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     // 4 MiB L2 together with the streaming A tiles; XCD x serves group x % ngroups for its share of the
     // row blocks, walking them column-fastest so the CUs of an XCD share A rows at any moment.
     //   seq = i * wg_per_group + rank   ->   (tm, tn) = (seq / ncols, c0 + seq % ncols)
-    const bool grouped = (gridDim.x & 7) == 0;                    // otherwise: one group, plain round-robin
+    const bool grouped = (gridDim.x & 7) == 0;                    // otherwise: one group, XCD-contiguous ranks (xcd_remap)
     const int ng = grouped ? ngroups : 1;
     const int xcd = grouped ? (int)(blockIdx.x & 7) : 0;
     const int in_xcd = grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int cpg = (tiles_n + ng - 1) / ng;                      // columns per group
     const int c0 = grp * cpg;
     const int ncols = min(cpg, tiles_n - c0);                     // may be <= 0 for a trailing empty group
-    const int rank = (xcd / ng) * per_xcd + in_xcd;               // XCD-major inside the group
+    const int rank = grouped ? (xcd / ng) * per_xcd + in_xcd      // XCD-major inside the group
+                             : xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int wg_per_group = grouped ? (8 / ng) * per_xcd : (int)gridDim.x;
     const int tiles_m1 = (g.M + 255) >> 8;
     const int tiles_m = tiles_m1 * nbatch;
@@ -335,15 +336,14 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     // CUs out of the grid while such work is in flight
     const int cus = aim_num_cus() - g_reserve_cus > 8 ? aim_num_cus() - g_reserve_cus : 8;
     int grid = tiles < cus ? tiles : cus;
-    // balanced grid: the smallest multiple of 8 workgroups that still finishes in ceil(tiles / cus) rounds.  1 182 tiles take
-    // 5 rounds on 256 CUs and on 240: the 16 CUs that would idle through the last round are free for the other streams
-    // for the whole launch instead.
+    // balanced grid: the fewest workgroups that still finish in ceil(tiles / cus) rounds.  1 182 tiles take 5 rounds on 256
+    // CUs and on 237: the 19 CUs that would idle through the last round are free for the other streams for the whole
+    // launch instead.
     static const bool balanced = [] { const char* e = getenv("AIM_GEMM_BALANCED"); return !e || atoi(e) != 0; }();
     if (balanced && tiles > cus) {
         const int rounds = (tiles + cus - 1) / cus;
         const int need = (tiles + rounds - 1) / rounds;
-        const int g8 = ((need + 7) / 8) * 8;
-        if (g8 < grid) grid = g8;
+        if (need < grid) grid = need;       // any size: without a multiple of 8 the kernel ranks its blocks by xcd_remap
     }
     // column groups: keep each group's weight slice (+ streaming A) inside an XCD's 4 MiB L2
     int ngroups = 1;
@@ -352,8 +352,6 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
         // measured on MI355X: <= 4 % gain on N >= 3072 and a loss whenever the groups are unbalanced, so the
         // default is one group; AIM_GEMM_GROUPS = 2 | 4 | 8 is kept for experiments
         if (force_groups == 2 || force_groups == 4 || force_groups == 8) ngroups = force_groups;
-    } else if (grid >= 8) {
-        grid = (grid / 8) * 8;     // XCD-aware schedule wants a multiple of 8; smaller grids use plain round-robin
     }
     static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew, g_probe, g_probe_cap);
