@@ -196,6 +196,7 @@ _LAMBDA_FUSED = os.environ.get("AIM_LAMBDA_FUSED", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
+_QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 _RESERVE_CUS = int(os.environ.get("AIM_RESERVE_CUS", "0"))      # CUs the persistent GEMMs leave free inside a fork
 
 
@@ -274,7 +275,7 @@ class _Fork:
         """Run ``calls`` (closures launching kernels) after the side stream's work so far, on a third stream that nothing
         waits for until ``join_detached``.  ``keep`` receives the closures so that the tensors they captured (allocated
         on other streams) outlive their use."""
-        if not calls:
+        if not calls or os.environ.get("AIM_X_SKIP_WGRAD"):      # (timing experiment only: gradients are then wrong)
             return
         if not (self.enabled and _DETACH_WGRAD):
             ctx = self.side() if self.enabled else None
@@ -400,7 +401,11 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
     ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
     qkv = _empty((M, 3 * D), BF16, dev)
+    if _QKV_RESERVE and _CLS_EARLY and fork.enabled:      # leave CUs to the class-token chain running beside this GEMM
+        ops.gemm_reserve_cus(_QKV_RESERVE)
     ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
+    if _QKV_RESERVE and _CLS_EARLY and fork.enabled:
+        ops.gemm_reserve_cus(0)
     del xl
     if not _CLS_EARLY:
         with fork.side():
