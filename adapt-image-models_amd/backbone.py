@@ -275,7 +275,7 @@ class _Fork:
         """Run ``calls`` (closures launching kernels) after the side stream's work so far, on a third stream that nothing
         waits for until ``join_detached``.  ``keep`` receives the closures so that the tensors they captured (allocated
         on other streams) outlive their use."""
-        if not calls or os.environ.get("AIM_X_SKIP_WGRAD"):      # (timing experiment only: gradients are then wrong)
+        if not calls:
             return
         if not (self.enabled and _DETACH_WGRAD):
             ctx = self.side() if self.enabled else None
