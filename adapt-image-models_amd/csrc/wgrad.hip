@@ -10,6 +10,7 @@
 // The M dimension is split over blockIdx.y in chunks; partial tiles go to a caller-provided scratch slab and
 // are summed by a second kernel (no atomics), or are combined with fp32 atomics when no scratch is given.
 #include "aim_common.h"
+#include <stdlib.h>
 #include "aim_kernels_internal.h"
 
 namespace {
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 }  // namespace
 
 static int wgrad_chunks(int M, int tiles, int* chunk_out) {
-    int nchunks = (256 + tiles - 1) / tiles;      // ~1 workgroup per CU
+    // Target workgroup count.  256 = one per CU is fastest stand-alone; the framework runs these launches on a stream
+    // of their own beside MFMA-bound GEMMs, where fewer, longer workgroups mean fewer partial slabs to write and sum.
+    static const int target = [] { const char* e = getenv("AIM_WGRAD_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+    int nchunks = (target + tiles - 1) / tiles;
     const int maxchunks = (M + MSTEP - 1) / MSTEP;
     if (nchunks > maxchunks) nchunks = maxchunks;
     int chunk = (M + nchunks - 1) / nchunks;
