@@ -166,9 +166,10 @@ def main():
         }
         roof = None
         if timing:
-            # launches of >= 10 GFLOP: the persistent 256x256 kernel (gemm256.hip) except the batched EXPSUM (gemm.hip)
+            # launches of >= 10 GFLOP: all on the persistent 256x256 kernel (gemm256.hip).  They are timed where they run: in
+            # the backward they share the chip with the detached weight-gradient stream (Streams)
             names = {0: "gemm256_kernel<EPI_BF16>", 1: "gemm256_kernel<EPI_ACT>", 2: "gemm256_kernel<EPI_DACT>",
-                     3: "gemm256_kernel<EPI_F32>", 4: "gemm_kernel<EPI_EXPSUM>"}
+                     3: "gemm256_kernel<EPI_F32>", 4: "gemm256_kernel<EPI_EXPSUM>"}
             summ = ops.GEMM_TIMER.summary()
             if summ:
                 tot_ms = sum(d["ms"] for d in summ.values())
