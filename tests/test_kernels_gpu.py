@@ -40,7 +40,10 @@ def quick_gelu(x):
                                    (394, 2304, 768), (130, 132, 72), (1, 4, 8),
                                    # M >= 1024 runs the 256x256 pipelined kernel (gemm256.hip)
                                    (1024, 256, 64), (2048, 768, 768), (1300, 200, 136), (1576, 3072, 192),
-                                   (1100, 128, 8), (3940, 192, 768), (1182, 768, 3072)])
+                                   (1100, 128, 8), (3940, 192, 768), (1182, 768, 3072),
+                                   # more tiles than CUs: balanced persistent grids that are not multiples of 8
+                                   # (300 tiles -> 150 workgroups; 903 tiles -> 226), several tiles per workgroup
+                                   (76800, 256, 64), (77000, 768, 72)])
 def test_gemm_bf16_plain(M, N, K):
     ops = _ops()
     a, w = rnd((M, K), 1, dtype=torch.bfloat16), rnd((N, K), 2, K ** -0.5, torch.bfloat16)
