@@ -217,7 +217,7 @@ def ref_embed(imgs: Tensor, st: State, num_frames: int) -> Tensor:
     x = imgs.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
     x = F.conv2d(x, st["conv1.weight"], None, stride=p)
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
-    cls = st["class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype)
+    cls = st["class_embedding"].to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype, device=x.device)
     x = torch.cat([cls, x], dim=1) + st["positional_embedding"].to(x.dtype)
     n = x.shape[1]
     x = x.reshape(B, T, n, -1).permute(0, 2, 1, 3).reshape(B * n, T, -1)
