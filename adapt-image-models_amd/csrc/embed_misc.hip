@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TDX* __restrict__ 
                                                         const float* __restrict__ cls, const float* __restrict__ pos,
                                                         const float* __restrict__ tmp, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ dtemporal, int B, int T, int N, int D) {
+                                                        float* __restrict__ dtemporal, float* __restrict__ partial, int B,
+                                                        int T, int N, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x, nch = D >> 2;
     f32x4 acc[NC];
@@ -168,6 +169,31 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TDX* __restrict__ 
             }
         }
     }
+    if (partial) {
+        // deterministic form: the block's four waves are summed in a fixed order through LDS and the block's partial row goes
+        // to partial[t][blockIdx.y][D]; embed_bwd_finish_kernel adds the rows up in order (no atomics anywhere)
+        __shared__ float red[3][NC * 256];
+        if (wave > 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = lane + c * 64;
+                if (ch < nch) *(f32x4*)(&red[wave - 1][ch * 4]) = acc[c];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ch = lane + c * 64;
+                if (ch < nch) {
+                    f32x4 a = acc[c];
+                    for (int w = 0; w < 3; ++w) a += *(const f32x4*)(&red[w][ch * 4]);
+                    *(f32x4*)(partial + ((long long)t * gridDim.y + blockIdx.y) * D + ch * 4) = a;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
@@ -176,6 +202,16 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TDX* __restrict__ 
             for (int e = 0; e < 4; ++e) atomicAdd(dtemporal + (long long)t * D + ch * 4 + e, acc[c][e]);
         }
     }
+}
+
+// dtemporal[t][c] += sum over the blocks' partial rows, in block order
+__global__ __launch_bounds__(256) void embed_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dtemporal,
+                                                               int chunks, int D) {
+    const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f;
+    for (int y = 0; y < chunks; ++y) a += partial[((long long)t * chunks + y) * D + c];
+    dtemporal[(long long)t * D + c] += a;
 }
 
 template <typename TX>
@@ -285,7 +321,8 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
     }
 }
 
-// stage 2: out[c] += sum_p partial[p][c]; grid (C/64, 16): 64 columns x 4 row-slots per block, 16 blocks per column
+// stage 2: out[c] += sum_p partial[p][c]; grid (C/64, 1): 64 columns x 4 row-slots per block, ONE block per column group, so
+// the sum has a fixed order and the update is a plain read-modify-write (bitwise reproducible; it runs off the critical path)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int P, int C) {
     __shared__ float red[256];
@@ -296,7 +333,7 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
         for (int p = blockIdx.y * 4 + slot; p < P; p += gridDim.y * 4) acc += partial[(long long)p * C + c];
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (slot == 0 && c < C) atomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (slot == 0 && c < C) out[c] += red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
@@ -440,24 +477,39 @@ extern "C" int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* 
 
 extern "C" int aim_embed_bwd(const void* dx, int dx_is_bf16, const aim_bf16* tok, const float* cls, const float* pos,
                              const float* temporal, const float* gamma, const float* mean, const float* rstd,
-                             float* dtemporal, int B, int T, int N, int D, void* stream) {
+                             float* dtemporal, int B, int T, int N, int D, float* workspace, int64_t workspace_bytes,
+                             void* stream) {
     AIM_CHECK_ARG(B > 0 && T > 0 && N > 1 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "embed_bwd: bad shape N=%d D=%d", N, D);
     AIM_CHECK_ARG(dx && tok && cls && pos && temporal && gamma && mean && rstd && dtemporal, "embed_bwd: null pointer");
     int chunks = (B * N + 3) / 4;
     const int want = (2048 + T - 1) / T;
     if (chunks > want) chunks = want;
+    // with scratch ([T][chunks][D] fp32, aim_embed_bwd_workspace_bytes) the reduction is two-stage and bitwise reproducible
+    float* partial = (workspace && workspace_bytes >= (int64_t)T * chunks * D * 4) ? workspace : nullptr;
 #define AIM_EB(NC)                                                                                                     \
     if (dx_is_bf16)                                                                                                    \
         hipLaunchKernelGGL((embed_bwd_kernel<NC, bf16_t>), dim3(T, chunks), dim3(256), 0, (hipStream_t)stream,          \
-                           (const bf16_t*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D); \
+                           (const bf16_t*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, partial, B, T, N, D); \
     else                                                                                                               \
         hipLaunchKernelGGL((embed_bwd_kernel<NC, float>), dim3(T, chunks), dim3(256), 0, (hipStream_t)stream,           \
-                           (const float*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N, D)
+                           (const float*)dx, (const bf16_t*)tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, partial, B, T, N, D)
     const int nc = (D + 255) / 256;
     if (nc <= 1) AIM_EB(1); else if (nc == 2) AIM_EB(2); else if (nc == 3) AIM_EB(3); else if (nc == 4) AIM_EB(4); else AIM_EB(8);
 #undef AIM_EB
     AIM_CHECK_LAUNCH("aim_embed_bwd");
+    if (partial) {
+        hipLaunchKernelGGL(embed_bwd_finish_kernel, dim3(T, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, dtemporal,
+                           chunks, D);
+        AIM_CHECK_LAUNCH("aim_embed_bwd(finish)");
+    }
     return 0;
+}
+
+extern "C" int64_t aim_embed_bwd_workspace_bytes(int B, int T, int N, int D) {
+    int chunks = (B * N + 3) / 4;
+    const int want = (2048 + T - 1) / T;
+    if (chunks > want) chunks = want;
+    return (int64_t)T * chunks * D * 4;
 }
 
 extern "C" int aim_frame_sum(const void* x, int x_is_bf16, const float* w, float* out, int frames, int ntok, int D, void* stream) {
@@ -479,6 +531,7 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
     if ((C % 8) == 0 && C <= 2048 && (ldx % 8) == 0) {
         int rpb8 = (M + 1023) / 1024;        // <= 1024 row blocks
         if (rpb8 < 64) rpb8 = 64;
+        if (M <= 2048) rpb8 = M;             // few rows: ONE block, the only writer of each column (fixed summation order)
         const int P = (M + rpb8 - 1) / rpb8;
         // two-stage (partials + finish) when the caller provides scratch; otherwise one atomic per column per block
         float* partial = (workspace && workspace_bytes >= (int64_t)P * C * 4 && P > 8) ? workspace : nullptr;
@@ -486,7 +539,7 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
                            ntok, out, partial, M, C, rpb8);
         AIM_CHECK_LAUNCH("aim_colsum_bf16");
         if (partial) {
-            hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 16), dim3(256), 0, (hipStream_t)stream, partial, out, P, C);
+            hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, partial, out, P, C);
             AIM_CHECK_LAUNCH("aim_colsum_bf16(finish)");
         }
         return 0;

@@ -152,6 +152,29 @@ extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     return 0;
 }
 
+namespace {
+// dgamma[c] += sum_r dy[r][c] * xhat[r][c], dbeta[c] += sum_r dy[r][c]: one thread per column walks the rows in order
+// (bitwise reproducible).  The path trains ln_post only (B*T rows), so the walk is short; beyond AIM_LN_DPARAM_ROWS rows the
+// main kernel's per-element atomics are used instead.
+template <typename TDY>
+__global__ __launch_bounds__(64) void ln_dparam_kernel(const TDY* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                      long long ldx, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int rows, int D) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= D) return;
+    float ag = 0.f, ab = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float d = (float)dy[(long long)r * lddy + c];
+        ag += d * ((x[(long long)r * ldx + c] - mean[r]) * rstd[r]);
+        ab += d;
+    }
+    dgamma[c] += ag;
+    dbeta[c] += ab;
+}
+constexpr int AIM_LN_DPARAM_ROWS = 8192;
+}  // namespace
+
 extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,
                                  aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int rows, int D,
@@ -160,6 +183,17 @@ extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, c
     AIM_CHECK_ARG(dy && x && gamma && mean && rstd && (dx || dx_bf16), "layernorm_bwd: null pointer");
     AIM_CHECK_ARG((!dgamma) == (!dbeta), "layernorm_bwd: dgamma and dbeta go together");
     AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
+    if (dgamma && rows <= AIM_LN_DPARAM_ROWS) {      // parameter gradients apart, in a fixed order
+        if (dy_is_bf16)
+            hipLaunchKernelGGL(ln_dparam_kernel<bf16_t>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                               (long long)lddy, x, (long long)ldx, mean, rstd, dgamma, dbeta, rows, D);
+        else
+            hipLaunchKernelGGL(ln_dparam_kernel<float>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)dy,
+                               (long long)lddy, x, (long long)ldx, mean, rstd, dgamma, dbeta, rows, D);
+        AIM_CHECK_LAUNCH("aim_layernorm_bwd(dparam)");
+        dgamma = nullptr;
+        dbeta = nullptr;
+    }
 #define AIM_LN_BWD_T(NC, TDY, TDR)                                                                                  \
     hipLaunchKernelGGL((ln_bwd_kernel<NC, TDY, TDR>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,        \
                        (const TDY*)dy, (long long)lddy, x, (long long)ldx, gamma, mean, rstd, (const TDR*)dres, dx,   \

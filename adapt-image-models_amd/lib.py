@@ -58,7 +58,8 @@ SIGNATURES = {
     "aim_lambda": [P, P, I, P, P, I, P, P, I, I, I, F, P],
     "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],
     "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
-    "aim_embed_bwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "aim_embed_bwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, P, L, P],
+    "aim_embed_bwd_workspace_bytes": [I, I, I, I],
     "aim_frame_sum": [P, I, P, P, I, I, I, P],
     "aim_colsum_bf16": [P, I, P, P, I, P, I, I, P, L, P],
     "aim_cast_bf16": [P, P, I, I, I, I, P],

@@ -239,9 +239,12 @@ def embed_bwd(dx, tok, cls, pos, temporal, gamma, mean, rstd, dtemporal, B, T, N
                    ("rstd", rstd), ("dtemporal", dtemporal)):
         _chk(t_, F32, n_)
     _chk(dx, dx.dtype if dx.dtype in (F32, BF16) else F32, "dx")
-    check(load_library().aim_embed_bwd(dx.data_ptr(), int(dx.dtype == BF16), tok.data_ptr(), cls.data_ptr(), pos.data_ptr(),
-                                       temporal.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                       dtemporal.data_ptr(), B, T, N, D, _stream()), "aim_embed_bwd")
+    lib = load_library()
+    nbytes = lib.aim_embed_bwd_workspace_bytes(B, T, N, D)
+    ws = torch.empty((nbytes // 4,), dtype=F32, device=dx.device)      # two-stage, bitwise reproducible reduction
+    check(lib.aim_embed_bwd(dx.data_ptr(), int(dx.dtype == BF16), tok.data_ptr(), cls.data_ptr(), pos.data_ptr(),
+                            temporal.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                            dtemporal.data_ptr(), B, T, N, D, ws.data_ptr(), nbytes, _stream()), "aim_embed_bwd")
 
 
 def frame_sum(x, w, out, frames, ntok, D):

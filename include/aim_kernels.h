@@ -179,7 +179,10 @@ int aim_embed_ln(const aim_bf16* tok, const float* cls, const float* pos, const 
                  int B, int T, int N, int D, float eps, void* stream);
 int aim_embed_bwd(const void* dx, int dx_is_bf16, const aim_bf16* tok, const float* cls, const float* pos,
                   const float* temporal, const float* gamma, const float* mean, const float* rstd,
-                  float* dtemporal, int B, int T, int N, int D, void* stream);
+                  float* dtemporal, int B, int T, int N, int D,
+                  float* workspace /* optional scratch: two-stage, bitwise reproducible reduction */, int64_t workspace_bytes,
+                  void* stream);
+int64_t aim_embed_bwd_workspace_bytes(int B, int T, int N, int D);
 
 /* ------------------------------------------------------------------------------------------
  * Small reductions / casts used by the block's backward and the optimizer boundary.
