@@ -321,19 +321,25 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
     }
 }
 
-// stage 2: out[c] += sum_p partial[p][c]; grid (C/64, 1): 64 columns x 4 row-slots per block, ONE block per column group, so
-// the sum has a fixed order and the update is a plain read-modify-write (bitwise reproducible; it runs off the critical path)
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int P, int C) {
-    __shared__ float red[256];
+// stage 2: out[c] += sum_p partial[p][c].  ONE block of 64 columns x 16 row-slots per column group: every sum has a fixed
+// order (slot s adds partials s, s+16, ...; the slots are added 0..15) and the update is a plain read-modify-write --
+// bitwise reproducible, no atomics; it runs off the critical path.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int P, int C) {
+    __shared__ float red[1024];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slot = threadIdx.x >> 6;
     float acc = 0.f;
     if (c < C)
-        for (int p = blockIdx.y * 4 + slot; p < P; p += gridDim.y * 4) acc += partial[(long long)p * C + c];
+        for (int p = slot; p < P; p += 16) acc += partial[(long long)p * C + c];
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (slot == 0 && c < C) out[c] += red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    if (slot == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) t += red[threadIdx.x + 64 * s2];
+        out[c] += t;
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
@@ -531,15 +537,20 @@ extern "C" int aim_colsum_bf16(const aim_bf16* X, int ldx, const float* af, cons
     if ((C % 8) == 0 && C <= 2048 && (ldx % 8) == 0) {
         int rpb8 = (M + 1023) / 1024;        // <= 1024 row blocks
         if (rpb8 < 64) rpb8 = 64;
-        if (M <= 2048) rpb8 = M;             // few rows: ONE block, the only writer of each column (fixed summation order)
-        const int P = (M + rpb8 - 1) / rpb8;
-        // two-stage (partials + finish) when the caller provides scratch; otherwise one atomic per column per block
-        float* partial = (workspace && workspace_bytes >= (int64_t)P * C * 4 && P > 8) ? workspace : nullptr;
+        int P = (M + rpb8 - 1) / rpb8;
+        // two-stage (partials + finish, fixed summation order) when the caller provides scratch; without scratch a small
+        // problem runs as ONE block (the only writer of each column) and a large one falls back to one atomic per
+        // column per block
+        float* partial = (workspace && workspace_bytes >= (int64_t)P * C * 4 && P > 1) ? workspace : nullptr;
+        if (!partial && M <= 2048) {
+            rpb8 = M;
+            P = 1;
+        }
         hipLaunchKernelGGL(colsum8_kernel, dim3(1, P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, af, at,
                            ntok, out, partial, M, C, rpb8);
         AIM_CHECK_LAUNCH("aim_colsum_bf16");
         if (partial) {
-            hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, partial, out, P, C);
+            hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, out, P, C);
             AIM_CHECK_LAUNCH("aim_colsum_bf16(finish)");
         }
         return 0;

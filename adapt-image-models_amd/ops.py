@@ -256,8 +256,8 @@ def frame_sum(x, w, out, frames, ntok, D):
 def colsum(X, out, *, af=None, at=None, ntok=0):
     _chk(X, BF16, "X"); _chk(out, F32, "out"); _chk(af, F32, "af"); _chk(at, F32, "at")
     ws = None
-    if X.shape[0] >= 4096:          # large reductions go two-stage through a scratch buffer (no atomics)
-        ws = torch.empty((1024, X.shape[1]), dtype=F32, device=X.device)
+    if X.shape[0] > 64:             # two-stage through a scratch buffer: no atomics, bitwise reproducible
+        ws = torch.empty((min(1024, (X.shape[0] + 63) // 64), X.shape[1]), dtype=F32, device=X.device)
     check(load_library().aim_colsum_bf16(X.data_ptr(), X.stride(0), _p(af), _p(at), ntok, out.data_ptr(),
                                          X.shape[0], X.shape[1], _p(ws), ws.numel() * 4 if ws is not None else 0,
                                          _stream()), "aim_colsum_bf16")
