@@ -111,6 +111,20 @@ __device__ __forceinline__ bf16x4 lds_read_tr4(const AIM_LDS char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AIM_LDS bf16x4*)p);
 }
 
+// Pair two packed 4 x bf16 groups (8 bytes each) that a lane holds for MFMA tiles dt and dt+1 into ONE 16-byte store:
+// v_permlane16_swap exchanges the odd 16-lane rows of the first operand with the even rows of the second, so an even-row
+// lane ends with 8 consecutive elements of tile dt (its own 4 + its odd neighbour's), an odd-row lane with 8 of tile dt+1.
+// Inline asm: the clang builtin for this instruction is miscompiled by this hipcc (tools/swap_probe.hip); `s_nop 1` covers
+// the VALU-write -> permlane-read hazard.  Returns the 16 bytes; the caller offsets the address by row parity.
+__device__ __forceinline__ bf16x8 pair_rows16(bf16x4 a, bf16x4 b) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+    unsigned a0 = ua[0], a1 = ua[1], b0 = ub[0], b1 = ub[1];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    return __builtin_bit_cast(bf16x8, u32x4_t{a0, a1, b0, b1});
+}
+
 // XCD-aware bijective remap of a linear block id (8 XCDs, blocks dealt round-robin): blocks that
 // share an XCD get a contiguous range of logical ids (cdna guide T1, bijective form).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -114,11 +114,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[dt], 0, 0, 0);
             }
         }
-        if (q < N) {
-            bf16_t* op = dqkv + ((long long)bt * N + q) * ld + h * 64 + fq * 4;
+        {   // 16-byte stores: tiles (dt, dt+1) paired across even / odd 16-lane rows (aim_common.h pair_rows16)
+            bf16_t* op = dqkv + ((long long)bt * N + (q < N ? q : 0)) * ld + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *(bf16x4*)(op + dt * 16) = pack4(dq[dt][0] * 0.125f, dq[dt][1] * 0.125f, dq[dt][2] * 0.125f, dq[dt][3] * 0.125f);
+            for (int dt = 0; dt < 4; dt += 2) {
+                const bf16x8 v = pair_rows16(
+                    pack4(dq[dt][0] * 0.125f, dq[dt][1] * 0.125f, dq[dt][2] * 0.125f, dq[dt][3] * 0.125f),
+                    pack4(dq[dt + 1][0] * 0.125f, dq[dt + 1][1] * 0.125f, dq[dt + 1][2] * 0.125f, dq[dt + 1][3] * 0.125f));
+                if (q < N) *(bf16x8*)(op + dt * 16) = v;
+            }
         }
     }
 }
@@ -263,13 +267,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int key = kp * 32 + u * 16 + frow;
-            if (key < N) {
-                bf16_t* op = dqkv + ((long long)bt * N + key) * ld + h * 64 + fq * 4;
+            // 16-byte stores: tiles (dt, dt+1) paired across even / odd 16-lane rows (aim_common.h pair_rows16)
+            bf16_t* op = dqkv + ((long long)bt * N + (key < N ? key : 0)) * ld + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    *(bf16x4*)(op + D + dt * 16) =
-                        pack4(dk[dt][u][0] * 0.125f, dk[dt][u][1] * 0.125f, dk[dt][u][2] * 0.125f, dk[dt][u][3] * 0.125f);
-                    *(bf16x4*)(op + 2 * D + dt * 16) = pack4(dv[dt][u][0], dv[dt][u][1], dv[dt][u][2], dv[dt][u][3]);
+            for (int dt = 0; dt < 4; dt += 2) {
+                const bf16x8 vk = pair_rows16(
+                    pack4(dk[dt][u][0] * 0.125f, dk[dt][u][1] * 0.125f, dk[dt][u][2] * 0.125f, dk[dt][u][3] * 0.125f),
+                    pack4(dk[dt + 1][u][0] * 0.125f, dk[dt + 1][u][1] * 0.125f, dk[dt + 1][u][2] * 0.125f, dk[dt + 1][u][3] * 0.125f));
+                const bf16x8 vv = pair_rows16(pack4(dv[dt][u][0], dv[dt][u][1], dv[dt][u][2], dv[dt][u][3]),
+                                              pack4(dv[dt + 1][u][0], dv[dt + 1][u][1], dv[dt + 1][u][2], dv[dt + 1][u][3]));
+                if (key < N) {
+                    *(bf16x8*)(op + D + dt * 16) = vk;
+                    *(bf16x8*)(op + 2 * D + dt * 16) = vv;
                 }
             }
         }

@@ -167,11 +167,16 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
             }
         }
         ATT_STAMPQ(3);
-        if (q < N) {
-            bf16_t* op = out + ((long long)bt * N + q) * D + h * 64 + fq * 4;
+        {
+            // 16-byte stores: tiles (dt, dt+1) are paired across the even / odd 16-lane rows (aim_common.h pair_rows16), so a
+            // lane writes 8 consecutive head-dim elements and a row's four lanes cover 64 contiguous bytes
+            bf16_t* op = out + ((long long)bt * N + (q < N ? q : 0)) * D + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *(bf16x4*)(op + dt * 16) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            for (int dt = 0; dt < 4; dt += 2) {
+                const bf16x8 v = pair_rows16(pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv),
+                                             pack4(o[dt + 1][0] * inv, o[dt + 1][1] * inv, o[dt + 1][2] * inv, o[dt + 1][3] * inv));
+                if (q < N) *(bf16x8*)(op + dt * 16) = v;
+            }
         }
         ATT_STAMPQ(4);
     }
