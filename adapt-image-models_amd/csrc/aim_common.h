@@ -111,6 +111,34 @@ __device__ __forceinline__ bf16x4 lds_read_tr4(const AIM_LDS char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AIM_LDS bf16x4*)p);
 }
 
+// x op x[lane ^ 16] and x op x[lane ^ 32] without the LDS crossbar (ds_bpermute): v_permlane16_swap / v_permlane32_swap on
+// two copies of x leave (own, partner) in the two registers on every lane, in an order that a commutative op ignores.
+__device__ __forceinline__ void lane_pair16(float x, float& a, float& b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_pair32(float x, float& a, float& b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// reductions over the four lanes {l, l^16, l^32, l^48}
+__device__ __forceinline__ float quad_max(float x) {
+    float a, b;
+    lane_pair16(x, a, b);
+    x = fmaxf(a, b);
+    lane_pair32(x, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    float a, b;
+    lane_pair16(x, a, b);
+    x = a + b;
+    lane_pair32(x, a, b);
+    return a + b;
+}
+
 // Pair two packed 4 x bf16 groups (8 bytes each) that a lane holds for MFMA tiles dt and dt+1 into ONE 16-byte store:
 // v_permlane16_swap exchanges the odd 16-lane rows of the first operand with the even rows of the second, so an even-row
 // lane ends with 8 consecutive elements of tile dt (its own 4 + its odd neighbour's), an odd-row lane with 8 of tile dt+1.

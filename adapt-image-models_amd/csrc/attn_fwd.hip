@@ -120,8 +120,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_max(mx);          // over the lane quartet of this query (permlane swaps, no LDS crossbar)
         const float mc = mx * C2;
         float sum = 0.f;
 #pragma unroll
@@ -132,8 +131,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
                 s[t][e] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = quad_sum(sum);
         const float inv = 1.0f / sum;
         if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx * 0.125f + __logf(sum);
 
