@@ -478,7 +478,9 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
              act2=ops.ACT_GELU, at=dms2, ntok=N)
     x2 = _empty((M, D), F32, dev)
     ops.gemm(hcat, fz.Wcat2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
-    a_s = hcat[:, H4:].contiguous() if save else None
+    # the adapter's activation slice stays a VIEW of hcat (wgrad takes a row stride): no copy kernel in the forward, at the
+    # price of keeping hcat (M x (4D + r) bf16) alive until this block's backward
+    a_s = hcat[:, H4:] if save else None
     del hcat
     ctx = None
     if save:
