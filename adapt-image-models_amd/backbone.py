@@ -172,6 +172,39 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+class _Arena:
+    """Memory for the tensors that the SIDE stream's kernels produce, allocated on the MAIN stream before the fork.
+
+    PyTorch's caching allocator ties a block to the stream that was current when it was allocated: a tensor created
+    inside ``torch.cuda.stream(side)`` and later read on the main stream would go back to the side stream's pool when
+    freed, where a new side-stream allocation could overwrite it while the main stream still reads it (only event
+    ordering, not the allocator, would protect it).  Everything the class-token chain allocates is small (B*T rows), so
+    each block carves those tensors out of ONE main-stream buffer instead; the buffer lives as long as any view of it
+    (the saved context keeps views until the block's backward)."""
+
+    def __init__(self, dev, nbytes: int):
+        self.dev, self.chunk = dev, int(nbytes)
+        self.buf = torch.empty(self.chunk, dtype=torch.uint8, device=dev)      # current stream == main stream here
+        self.off = 0
+        self.main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * _ELEM[dtype] + 255) // 256 * 256
+        if self.off + nbytes > self.buf.numel():           # rare: grow, still on the main stream's pool
+            with torch.cuda.stream(self.main):
+                self.buf = torch.empty(max(self.chunk, nbytes), dtype=torch.uint8, device=self.dev)
+            self.off = 0
+        v = self.buf[self.off:self.off + nbytes].view(dtype)[:n].view(shape)
+        self.off += nbytes
+        return v
+
+
+_ELEM = {BF16: 2, F32: 4}
+
+
 # The class-token path of a block (temporal attention, T_/S_Adapter, the cross term: a dozen GEMMs on
 # B*T = 512 rows) occupies a few CUs for ~100 us.  It runs on a second HIP stream beside the spatial
 # attention kernels, which do not depend on it; the two are joined with events before `lamda`.
@@ -197,7 +230,6 @@ _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
-_RESERVE_CUS = int(os.environ.get("AIM_RESERVE_CUS", "0"))      # CUs the persistent GEMMs leave free inside a fork
 
 
 class _Fork:
@@ -249,8 +281,6 @@ class _Fork:
                 if fork.enabled:
                     if not fork.started:
                         fork.started = True
-                        if _RESERVE_CUS:    # persistent GEMMs launched until join() leave room for the side stream's kernels
-                            ops.gemm_reserve_cus(_RESERVE_CUS)
                         fork.sync_side_to_main()
                     self_inner.ctx = torch.cuda.stream(fork.side_stream)
                     self_inner.ctx.__enter__()
@@ -337,8 +367,6 @@ class _Fork:
 
     def join(self):
         if self.enabled and self.started:
-            if _RESERVE_CUS:
-                ops.gemm_reserve_cus(0)
             done = torch.cuda.Event()
             done.record(self.side_stream)
             if _JOIN_STATS is not None:      # diagnostics: how long the main stream sits in this wait
@@ -354,11 +382,11 @@ class _Fork:
 # ----------------------------------------------------------------------------------------------
 # one block: forward / backward on raw buffers
 # ----------------------------------------------------------------------------------------------
-def _adapter_fwd_small(x_bf, ad: _AdapterW, rows, r, D, dev, out_f32: bool):
+def _adapter_fwd_small(x_bf, ad: _AdapterW, rows, r, D, ar: _Arena, out_f32: bool):
     """Adapter on a few rows (class-token / per-frame vectors): D_fc1 -> GELU(erf) -> D_fc2."""
-    pre, h = _empty((rows, r), BF16, dev), _empty((rows, r), BF16, dev)
+    pre, h = ar.take((rows, r), BF16), ar.take((rows, r), BF16)
     ops.gemm(x_bf, ad.W1, ops.EPI_ACT, h, bias=ad.b1, out2=pre, act=ops.ACT_GELU)
-    out = _empty((rows, D), F32 if out_f32 else BF16, dev)
+    out = ar.take((rows, D), F32 if out_f32 else BF16)
     ops.gemm(h, ad.W2, ops.EPI_F32 if out_f32 else ops.EPI_BF16, out, bias=ad.b2)
     return out, pre, h
 
@@ -373,27 +401,29 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     # then the cross term.  It needs q/k/v of the B*T class rows only, so those are projected apart (ln_1 + QKV on
     # 512 rows) and the chain starts beside the big ln_1 / QKV GEMM instead of after them (AIM_CLS_EARLY=0: after).
     fork = _Fork(dev, "fwd")
+    # every tensor a side-stream kernel writes comes out of this main-stream buffer (see _Arena)
+    ar = _Arena(dev, 48 * BT * D + 4 * B * H * T * T + 8 * BT * N + (1 << 16))
 
     def cls_chain(qkv_src, n_stride):
-        ot = _empty((BT, D), BF16, dev)
-        probs = _empty((B, H, T, T), F32, dev)
+        ot = ar.take((BT, D), BF16)
+        probs = ar.take((B, H, T, T), F32)
         ops.cls_attn_fwd(qkv_src, ot, probs, B, T, n_stride, H)
-        ta = _empty((BT, D), BF16, dev)
+        ta = ar.take((BT, D), BF16)
         ops.gemm(ot, fz.Wo, ops.EPI_BF16, ta, bias=fz.bo)
-        xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, dev, out_f32=False)
+        xt, t_pre, t_h = _adapter_fwd_small(ta, adp["T_Adapter"], BT, r, D, ar, out_f32=False)
         # cross-attention to the single key/value xt[bt] (:265): softmax == 1, so crs = out_proj(W_v xt + b_v)
-        kv = _empty((BT, 2 * D), BF16, dev)
+        kv = ar.take((BT, 2 * D), BF16)
         ops.gemm(xt, fz.Wqkv[D:], ops.EPI_BF16, kv, bias=fz.bqkv[D:])
-        crs = _empty((BT, D), F32, dev)
+        crs = ar.take((BT, D), F32)
         ops.gemm(kv[:, D:], fz.Wo, ops.EPI_F32, crs, bias=fz.bo)
         return probs, ta, t_pre, t_h, kv, crs
 
     if _CLS_EARLY:
         with fork.side():
-            xl_cls = _empty((BT, D), BF16, dev)
-            ops.layernorm_fwd(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls, mean=_empty((BT,), F32, dev),
-                              rstd=_empty((BT,), F32, dev))
-            qkv_cls = _empty((BT, 3 * D), BF16, dev)
+            xl_cls = ar.take((BT, D), BF16)
+            ops.layernorm_fwd(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls, mean=ar.take((BT,), F32),
+                              rstd=ar.take((BT,), F32))
+            qkv_cls = ar.take((BT, 3 * D), BF16)
             ops.gemm(xl_cls, fz.Wqkv, ops.EPI_BF16, qkv_cls, bias=fz.bqkv)
             probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv_cls, 1)      # "N = 1": the rows ARE the class tokens
     # main stream: ln_1 (once) + fused QKV projection
@@ -401,11 +431,9 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
     ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
     qkv = _empty((M, 3 * D), BF16, dev)
-    if _QKV_RESERVE and _CLS_EARLY and fork.enabled:      # leave CUs to the class-token chain running beside this GEMM
-        ops.gemm_reserve_cus(_QKV_RESERVE)
-    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv)
-    if _QKV_RESERVE and _CLS_EARLY and fork.enabled:
-        ops.gemm_reserve_cus(0)
+    # this launch leaves CUs to the class-token chain running beside it (a per-call argument, not library state)
+    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv,
+             reserve_cus=_QKV_RESERVE if (_CLS_EARLY and fork.enabled) else 0)
     del xl
     if not _CLS_EARLY:
         with fork.side():
@@ -426,7 +454,7 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         if _LAMBDA_ON_SIDE and _CLS_EARLY:
             fork.sync_side_to_main()
             with fork.side():
-                ss = _empty((BT, N), F32, dev)
+                ss = ar.take((BT, N), F32)
                 ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
         nt = ops.expsum_tiles(N, N)
         part = _empty((BT, nt, 2), F32, dev)
@@ -438,15 +466,15 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         part_ready = fork.run_beside(expsum) if _EXPSUM_DETACHED else expsum()
 
     def lamda_chain():
-        lam, oml = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
+        lam, oml = ar.take((BT,), F32), ar.take((BT,), F32)
         if fused:
             ops.lambda_partials(part, lam, oml, BT)
         else:
             ops.lambda_(qkv, kv, part, nt, lam, oml, BT, N, D, 0.125, ss=ss)
         # S_Adapter(lamda * crs_attn): a per-frame vector broadcast over tokens (:275)
-        sin = _empty((BT, D), BF16, dev)
+        sin = ar.take((BT, D), BF16)
         ops.scale_rows(crs, lam, y=sin)
-        return (lam, oml, sin) + _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, dev, out_f32=True)
+        return (lam, oml, sin) + _adapter_fwd_small(sin, adp["S_Adapter"], BT, r, D, ar, out_f32=True)
 
     if _LAMBDA_ON_SIDE:               # the chain runs beside the spatial attention instead of after it
         if part_ready is not None:
@@ -490,14 +518,14 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     return x2, ctx
 
 
-def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, dev, need_dx_bf16: bool, later: list):
+def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, ar: _Arena, need_dx_bf16: bool, later: list):
     """Backward of an adapter on a few rows; returns d(input).  Its 4 parameter gradients are not on the gradient
     path: the two wgrad calls are appended to ``later`` (run by the caller off the critical stream)."""
     later.append(lambda: ops.wgrad(dout_bf, h, grads["D_fc2.weight"], grads["D_fc2.bias"]))
-    dpre = _empty((rows, r), BF16, dev)
+    dpre = ar.take((rows, r), BF16)
     ops.gemm(dout_bf, ad.W2T, ops.EPI_DACT, dpre, aux=pre, act=ops.ACT_GELU)
     later.append(lambda: ops.wgrad(dpre, a_in, grads["D_fc1.weight"], grads["D_fc1.bias"]))
-    din = _empty((rows, D), BF16 if need_dx_bf16 else F32, dev)
+    din = ar.take((rows, D), BF16 if need_dx_bf16 else F32)
     ops.gemm(dpre, ad.W1T, ops.EPI_BF16 if need_dx_bf16 else ops.EPI_F32, din)
     return din
 
@@ -540,31 +568,32 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
     later: list = big_later       # the adapters' weight gradients: nobody downstream waits for them
+    ar = _Arena(dev, 48 * BT * D + (1 << 16))      # side-stream tensors live in main-stream memory (see _Arena)
     with _Fork(dev, "bwd") as fork:
-        dsv = _empty((BT, D), F32, dev)
+        dsv = ar.take((BT, D), F32)
         ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
         # S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
-        dsv_b = _empty((BT, D), BF16, dev)
+        dsv_b = ar.take((BT, D), BF16)
         ops.cast_bf16(dsv, dsv_b)
         dsin = _adapter_bwd_small(dsv_b, adp["S_Adapter"], c["sin"], c["s_pre"], c["s_h"], grads["S_Adapter"], BT, r,
-                                  D, dev, need_dx_bf16=False, later=later)
-        dcrs = _empty((BT, D), BF16, dev)
+                                  D, ar, need_dx_bf16=False, later=later)
+        dcrs = ar.take((BT, D), BF16)
         ops.scale_rows(dsin, c["lam"], y=dcrs)
-        dvx = _empty((BT, D), BF16, dev)
+        dvx = ar.take((BT, D), BF16)
         ops.gemm(dcrs, fz.WoT, ops.EPI_BF16, dvx)
-        dxt = _empty((BT, D), BF16, dev)
+        dxt = ar.take((BT, D), BF16)
         ops.gemm(dvx, fz.WqkvT[:, 2 * D:], ops.EPI_BF16, dxt)
         # T_Adapter and out_proj of the temporal attention over class tokens
         dta = _adapter_bwd_small(dxt, adp["T_Adapter"], c["ta"], c["t_pre"], c["t_h"], grads["T_Adapter"], BT, r, D,
-                                 dev, need_dx_bf16=True, later=later)
-        dot = _empty((BT, D), BF16, dev)
+                                 ar, need_dx_bf16=True, later=later)
+        dot = ar.take((BT, D), BF16)
         ops.gemm(dta, fz.WoT, ops.EPI_BF16, dot)
         # the class rows' share of d(qkv) and its QKV dgrad stay on the side stream: the main stream's big dgrad GEMM
         # below does not wait for the class-token chain
         if _LATE_JOIN:
-            dqkv_cls = _empty((BT, 3 * D), BF16, dev)
+            dqkv_cls = ar.take((BT, 3 * D), BF16)
             ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv_cls, B, T, N, H, compact=True)
-            dxl_cls = _empty((BT, D), F32, dev)
+            dxl_cls = ar.take((BT, D), F32)
             ops.gemm(dqkv_cls, fz.WqkvT, ops.EPI_F32, dxl_cls)
     if keep is None:       # stand-alone use: the weight gradients are complete when this function returns
         keep = []
@@ -602,7 +631,7 @@ class _BackboneFn(torch.autograd.Function):
     the 12 adapter tensors of every layer (the reference's trainable set, vit_clip.py:413-415)."""
 
     @staticmethod
-    def forward(ctx, model: "ViT_CLIP", imgs: torch.Tensor, *params: torch.Tensor):
+    def forward(ctx, model: "ViT_CLIP", grad_enabled: bool, imgs: torch.Tensor, *params: torch.Tensor):
         L, H = model.layers, model.heads
         B, C, T, Hh, Ww = imgs.shape
         D, p = model.width, model.patch_size
@@ -611,7 +640,9 @@ class _BackboneFn(torch.autograd.Function):
         BT, M = B * T, B * T * N
         dev = imgs.device
         temporal, lnp_w, lnp_b = params[0], params[1], params[2]
-        need_grad = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        # grad mode is off inside Function.forward and needs_input_grad stays True under torch.no_grad(): the caller's
+        # grad mode decides whether the per-block contexts (~2 GB per ViT-B layer at 64 clips) are kept
+        need_grad = grad_enabled and any(ctx.needs_input_grad)
         frozen = model._frozen_operands()
         model._stage_adapters(frozen, params)      # ONE launch casts all 36 adapters' weights to bf16 operands
         adp = []
@@ -714,7 +745,7 @@ class _BackboneFn(torch.autograd.Function):
             elif grads_out[k] is not None and grads_out[k].dtype != p_.dtype:
                 grads_out[k] = grads_out[k].to(p_.dtype)
         ctx.saved = None
-        return (None, None) + tuple(grads_out)
+        return (None, None, None) + tuple(grads_out)
 
 
 @BACKBONES.register_module()
@@ -888,5 +919,5 @@ class ViT_CLIP(nn.Module):
         if x.dtype == torch.float16:
             x = x.float()
         x = x.contiguous()
-        y = _BackboneFn.apply(self, x, *self._trainable_list())     # [B, D, T]
+        y = _BackboneFn.apply(self, torch.is_grad_enabled(), x, *self._trainable_list())     # [B, D, T]
         return y.unsqueeze(-1).unsqueeze(-1)                          # BDTHW for I3D head (:456)

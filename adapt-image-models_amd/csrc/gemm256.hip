@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
                                             (g.xrow ? 32 : 16) + wave * 2);
         else
             wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
-        if (probe) {        // diagnostics (aim_gemm_probe): per-tile timestamps of wave 0, 100 MHz ticks
+        if (probe) {        // diagnostics (aim_gemm_args.probe): per-tile timestamps of wave 0, 100 MHz ticks
             const int slot = probe_i * (int)gridDim.x + (int)blockIdx.x;
             if (tid == 0 && slot < probe_cap) {
                 probe[slot * 4 + 0] = (unsigned long long)blockIdx.x | ((tc1 - tc0) << 16);   // K-loop shader cycles
@@ -320,10 +320,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }
 
-unsigned long long* g_probe = nullptr;
-int g_probe_cap = 0;
-int g_reserve_cus = 0;      // CUs the persistent grid leaves free (aim_gemm_reserve_cus)
-
 template <int EPI>
 int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
@@ -334,7 +330,8 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256) * nbatch;
     // a persistent grid that fills every CU starves whatever runs beside it on another stream: the caller can keep a few
     // CUs out of the grid while such work is in flight
-    const int cus = aim_num_cus() - g_reserve_cus > 8 ? aim_num_cus() - g_reserve_cus : 8;
+    const int reserve = g.reserve_cus > 0 ? g.reserve_cus : 0;       // per-call knob (aim_gemm_args.reserve_cus)
+    const int cus = aim_num_cus() - reserve > 8 ? aim_num_cus() - reserve : 8;
     int grid = tiles < cus ? tiles : cus;
     // balanced grid: the fewest workgroups that still finish in ceil(tiles / cus) rounds.  1 182 tiles take 5 rounds on 256
     // CUs and on 237: the 19 CUs that would idle through the last round are free for the other streams for the whole
@@ -354,25 +351,13 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
         if (force_groups == 2 || force_groups == 4 || force_groups == 8) ngroups = force_groups;
     }
     static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew, g_probe, g_probe_cap);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew,
+                       (unsigned long long*)g.probe, g.probe ? g.probe_cap : 0);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }
 
 }  // namespace
-
-extern "C" int aim_gemm_reserve_cus(int n) {
-    g_reserve_cus = n > 0 ? n : 0;
-    return 0;
-}
-
-// diagnostics: while a buffer is set, every gemm256 launch records {workgroup, tile start, K-loop end, epilogue end}
-// (100 MHz ticks) per tile into buf[capacity][4]; pass null to switch it off
-extern "C" int aim_gemm_probe(void* buf, int capacity) {
-    g_probe = (unsigned long long*)buf;
-    g_probe_cap = buf ? capacity : 0;
-    return 0;
-}
 
 int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st) {
     AIM_CHECK_ARG((long long)256 * g.lda * 2 < 0x7fffffffLL && (long long)256 * g.ldw * 2 < 0x7fffffffLL, "gemm256: leading dimension too large");

@@ -29,6 +29,7 @@ class GemmArgs(Structure):
         ("out", c_void_p), ("ldo", c_int32), ("out2", c_void_p), ("ldo2", c_int32),
         ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32), ("n_split", c_int32), ("act2", c_int32),
         ("xrow", c_void_p), ("ldx", c_int32),
+        ("reserve_cus", c_int32), ("probe", c_void_p), ("probe_cap", c_int32),
     ]
 
 
@@ -43,8 +44,6 @@ SIGNATURES = {
     "aim_last_error": [],
     "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
     "aim_gemm_expsum_tiles": [I, I],
-    "aim_gemm_probe": [P, I],
-    "aim_gemm_reserve_cus": [I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
@@ -69,7 +68,7 @@ SIGNATURES = {
     "aim_cast_multi": [P, I, P],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def load_library():

@@ -70,7 +70,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
          scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
          stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldv: Optional[int] = None, n_split: int = 0,
-         act2: int = 0, xrow=None):
+         act2: int = 0, xrow=None, reserve_cus: int = 0, probe=None):
     """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
     lib = load_library()
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -101,6 +101,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     _chk(xrow, BF16, "xrow")
     g.xrow = _p(xrow)
     g.ldx = xrow.stride(0) if xrow is not None else 0
+    g.reserve_cus = int(reserve_cus)       # per-call: CUs this persistent launch leaves to other streams
+    if probe is not None:                  # diagnostics (tools/probe_gemm.py): [cap, 4] int64 device tensor
+        g.probe, g.probe_cap = probe.data_ptr(), probe.shape[0]
     if epi in (EPI_BF16, EPI_ACT, EPI_DACT):
         _chk(out, BF16, "out")
     else:
@@ -155,11 +158,6 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=No
                                            mean.data_ptr(), rstd.data_ptr(), _p(dres),
                                            int(dres is not None and dres.dtype == BF16), _p(dx), _p(dx_bf16), lddx,
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
-
-
-def gemm_reserve_cus(n: int):
-    """Persistent GEMM grids leave ``n`` CUs free until called again with 0 (see aim_gemm_reserve_cus)."""
-    check(load_library().aim_gemm_reserve_cus(int(n)), "aim_gemm_reserve_cus")
 
 
 def attn_fwd(qkv, out, lse, BT, N, H):

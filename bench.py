@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6        # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md: ~2.5 PF)
 GF_PER_CLIP = {"fwd": 293.1, "bwd": 314.0}   # SURVEY section 8(d), ViT-B/16 T=8, algorithmic
+GF_PER_CLIP_L14_T16 = 5608.5                 # SURVEY section 8(d), ViT-L/14 T=16 fwd+bwd, algorithmic
+ARCH = {"B16": dict(patch_size=16, width=768, layers=12, heads=12),
+        "L14": dict(patch_size=14, width=1024, layers=24, heads=16)}     # configs/recognition/vit/vitclip_{base,large}_k400.py
 
 
 def parse():
@@ -32,16 +35,18 @@ def parse():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the ViT-L/14 16-frame block (BASELINE configs[3] shape)")
     return ap.parse_args()
 
 
-def build_model(frames, dev):
+def build_model(frames, dev, arch="B16"):
     import aim_amd
+    a = ARCH[arch]
     cfg = dict(
         type='Recognizer3D',
-        backbone=dict(type='ViT_CLIP', input_resolution=224, patch_size=16, num_frames=frames, width=768, layers=12,
-                      heads=12, drop_path_rate=0.2, adapter_scale=0.5, pretrained=None),
-        cls_head=dict(type='I3DHead', in_channels=768, num_classes=400, spatial_type='avg', dropout_ratio=0.5),
+        backbone=dict(type='ViT_CLIP', input_resolution=224, num_frames=frames, drop_path_rate=0.2, adapter_scale=0.5,
+                      pretrained=None, **a),
+        cls_head=dict(type='I3DHead', in_channels=a["width"], num_classes=400, spatial_type='avg', dropout_ratio=0.5),
         test_cfg=dict(average_clips='prob'))
     torch.manual_seed(0)
     model = aim_amd.build_model(cfg)
@@ -56,7 +61,20 @@ def cpu_baseline(frames):
     """The CPU oracle (literal restatement of the reference forward, pinned by tests/golden) timed on the
     host cores: 1 clip, fp32, fwd + bwd of backbone + head + CE.  Bounded sample (~10-30 s)."""
     from oracle import vit_clip_oracle as O
-    threads = min(os.cpu_count() or 1, 16)
+    # every core this process may run on (affinity mask, capped by a cgroup CPU quota when one is set)
+    logical = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    threads = max(1, min(allowed, quota) if quota else allowed)
     torch.set_num_threads(threads)
     st = O.synth_state_dict(O.backbone_param_shapes(224, frames, 16, 768, 12), seed=0)
     names = O.trainable_names(st)
@@ -80,6 +98,17 @@ def cpu_baseline(frames):
         step()
         times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
+    # BASELINE configs[0]: ViT-B/16 + AIM, 2 frames, batch 1, fp32 forward (the reference's own CPU-runnable case)
+    st1 = O.synth_state_dict(O.backbone_param_shapes(224, 2, 16, 768, 12), seed=0)
+    imgs1 = torch.randn(1, 3, 2, 224, 224)
+    with torch.no_grad():
+        O.ref_backbone(imgs1, st1, 12, 2)
+        t1 = []
+        for _ in range(5):
+            t0 = time.time()
+            O.ref_backbone(imgs1, st1, 12, 2)
+            t1.append(time.time() - t0)
+    cfg1 = sorted(t1)[2]
     model_name = "?"
     try:
         for line in open("/proc/cpuinfo"):
@@ -89,7 +118,56 @@ def cpu_baseline(frames):
     except OSError:
         pass
     return dict(value=round(1.0 / med, 4), unit="clips/s", cores=threads, kind="port",
-                sample=f"1 clip x {len(times)} steps (median), ViT-B/16 T={frames} fp32 fwd+bwd+head on {model_name}")
+                sample=f"1 clip x {len(times)} steps (median), ViT-B/16 T={frames} fp32 fwd+bwd+head on {model_name} "
+                       f"({logical} logical CPUs, {allowed} in the affinity mask, cgroup quota {quota}; {threads} threads used)",
+                cfg1_forward_s=round(cfg1, 4),
+                cfg1_sample="BASELINE configs[0]: ViT-B/16 + AIM, 2 frames 224^2, batch 1, fp32 forward, median of 5")
+
+
+def secondary_l14(dev, rank, world, steps=3, warmup=1, clips=32, frames=16):
+    """BASELINE configs[3] per-GPU shape: ViT-L/14 + AIM, 16 frames, 32 clips per GPU, the same train step
+    (fwd + bwd + adapter-grad all-reduce + AdamW), timed like the primary (barrier + synchronize, max over ranks)."""
+    from aim_amd.dist import broadcast_module, build_optimizer
+    model = build_model(frames, dev, "L14")
+    broadcast_module(model)
+    opt = build_optimizer(model, dict(type='AdamW', lr=3e-4, betas=(0.9, 0.999), weight_decay=0.05))
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    imgs = torch.randn((clips, 1, 3, frames, 224, 224), generator=g).to(dev)
+    label = torch.randint(0, 400, (clips, 1), generator=g).to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = model(imgs, label, return_loss=True)["loss_cls"]
+        loss.backward()
+        opt.all_reduce_grads()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    value = clips * world * steps / dt
+    return {"workload": "BASELINE configs[3] per-GPU shape: ViT-L/14 + AIM adapters, 16 frames 224^2, 32 clips/GPU, "
+                        "fwd+bwd+AdamW, drop_path 0.2, head dropout 0.5, synthetic",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 2), "global_batch": clips * world,
+            "mfma_frac_whole_step": round(value / world * GF_PER_CLIP_L14_T16 / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "loss": round(float(loss.detach()), 4),
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
 
 
 def main():
@@ -177,14 +255,20 @@ def main():
                 dom = max(summ, key=lambda k: summ[k]["ms"])
                 d = summ[dom]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                traffic = None     # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
-                try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))["kernels"]
-                    traffic = round(tj["gemm256_kernel<%d>" % dom]["hbm_bytes_per_launch"])
-                except Exception:
-                    pass
+                # HBM-side bytes per launch of that kernel: NOT measured in this run -- read from the committed PMC
+                # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, profiles/)
+                traffic, traffic_src = None, None
+                for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+                    try:
+                        tj = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+                        traffic = round(tj["gemm256_kernel<%d>" % dom]["hbm_bytes_per_launch"])
+                        traffic_src = "profiles/" + name + " (committed PMC passes, not this run)"
+                        break
+                    except Exception:
+                        pass
                 roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "launches_per_step": d["launches"] / args.steps,
                         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "flops_per_launch": d["flops"] / d["launches"],
@@ -196,6 +280,19 @@ def main():
                                                    "launches_per_step": v["launches"] / args.steps}
                                         for k, v in sorted(summ.items())}}
         out["roofline"] = roof
+    # second shape (after the primary timed region; every rank takes part)
+    sec = None
+    if not args.no_secondary and args.frames == 8:
+        del model, opt, imgs, label, losses
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        try:
+            sec = secondary_l14(dev, rank, world)
+        except Exception as e:          # the primary line must still be printed
+            sec = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    if rank == 0:
+        out["secondary"] = sec
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.frames)
         print(json.dumps(out), flush=True)
     if world > 1:

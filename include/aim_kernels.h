@@ -10,7 +10,9 @@
  * Conventions
  *   - every function returns 0 on success; non-zero -> aim_last_error() (thread-local text);
  *   - all pointers are DEVICE pointers unless said otherwise; the caller owns all memory
- *     (no allocation, no global state, no implicit synchronisation inside the library);
+ *     (no allocation, no mutable global state, no implicit synchronisation inside the library:
+ *     every knob of a launch is an argument of that call, so two host threads may drive two
+ *     streams through the library at once);
  *   - `stream` is a hipStream_t passed as void*; launches are stream-ordered;
  *   - matrices are row-major; "bf16" is IEEE bfloat16 stored as uint16_t; "ld*" are row strides
  *     in ELEMENTS;
@@ -29,7 +31,7 @@ extern "C" {
 
 typedef uint16_t aim_bf16;
 
-#define AIM_ABI_VERSION 1
+#define AIM_ABI_VERSION 2
 
 int aim_version(void);                /* == AIM_ABI_VERSION */
 const char* aim_last_error(void);     /* message of the last failing call on this thread */
@@ -84,30 +86,31 @@ typedef struct aim_gemm_args {
        8..15 of the item's 16 (max, sum) slots -- lamda's `cw` rides along with its `ow` (vit_clip.py:149-151,184-186). */
     const aim_bf16* xrow;
     int32_t ldx;
+    /* Scheduling knob of THIS launch (no reference counterpart): the large-tile GEMM is persistent (one workgroup per
+       CU); with reserve_cus > 0 its grid leaves that many CUs free, so that kernels queued on ANOTHER stream (the
+       class-token chain beside the QKV projection) are not starved. */
+    int32_t reserve_cus;
+    /* Diagnostics of THIS launch (tools/probe_gemm.py only): when probe != NULL (device memory, probe_cap x 4 uint64)
+       the large-tile kernel records {workgroup | K-loop cycles, tile start, K-loop end, epilogue end} (100 MHz ticks)
+       per processed tile. */
+    void* probe;
+    int32_t probe_cap;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
 /* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
 int aim_gemm_expsum_tiles(int M, int N);
 
-/* The large-tile GEMM is persistent (one workgroup per CU).  While `n` > 0, its grid leaves `n` CUs free so that
- * kernels queued on ANOTHER stream (the class-token chain beside the spatial attention) are not starved.  Host-side
- * state read at launch time; call with 0 to restore.  No reference counterpart. */
-int aim_gemm_reserve_cus(int n);
-
-/* Diagnostics (no reference counterpart): while `buf` (device memory, capacity x 4 uint64) is set, every
- * large-tile GEMM launch records {workgroup, tile start, K-loop end, epilogue end} in 100 MHz ticks per
- * processed tile.  Pass NULL to switch it off.  Used by tools/probe_gemm.py only. */
-int aim_gemm_probe(void* buf, int capacity);
-
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM for the (trainable) adapters:
- *   dW[n][k] += sum_m G[m][n] * A[m][k]      db[n] += sum_m G[m][n]        (fp32 atomics)
+ *   dW[n][k] += sum_m G[m][n] * A[m][k]      db[n] += sum_m G[m][n]
+ * With a workspace the split-M partial slabs are summed in a fixed order by a second kernel (no atomics, bitwise
+ * reproducible: the form the training step uses); workspace == NULL falls back to fp32 atomics.
  * autograd counterpart of Adapter.D_fc1 / D_fc2 (vit_clip.py:57-58).  Nw, Kw multiples of 8.
  * ------------------------------------------------------------------------------------------ */
 int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw,
                    float* db, int M, int Nw, int Kw,
-                   float* workspace /* optional: aim_wgrad_workspace_bytes(); NULL -> fp32 atomics */,
+                   float* workspace /* optional: aim_wgrad_workspace_bytes(); NULL -> fp32 atomics (not reproducible) */,
                    int64_t workspace_bytes, void* stream);
 int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw);
 
@@ -115,7 +118,8 @@ int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw);
  * LayerNorm (fp32 statistics, eps inside rsqrt) -- vit_clip.py:71-77 (ln_1, ln_2, ln_pre, ln_post)
  *   fwd: y = (x - mean) * rstd * gamma + beta ; x fp32 rows with stride ldx; y as bf16 and/or f32
  *   bwd: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma   (frozen gamma)
- *        optional: dgamma/dbeta accumulation (fp32 atomics) for the trainable ln_post.
+ *        optional: dgamma/dbeta accumulation for the trainable ln_post (rows <= 4096: one ordered column pass,
+ *        no atomics; more rows: per-element fp32 atomics).
  * ------------------------------------------------------------------------------------------ */
 int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                       aim_bf16* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
@@ -170,7 +174,8 @@ int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* s
  *             to a multiple of 64 with zeros (conv1 as a GEMM against conv1.weight.view(D,-1)).
  *   embed_ln: tok [B*T*G*G, D] bf16 + class/positional/temporal embeddings -> ln_pre ->
  *             x [B*T, N, D] f32 ; saves mean/rstd [B*T*N].
- *   embed_bwd: d(temporal_embedding)[T, D] += sum_{b,n} ln_pre_bwd(dx)  (fp32 atomics).
+ *   embed_bwd: d(temporal_embedding)[T, D] += sum_{b,n} ln_pre_bwd(dx)  (two-stage ordered reduction through the
+ *             workspace; workspace == NULL: fp32 atomics).
  * ------------------------------------------------------------------------------------------ */
 int aim_patchify(const void* imgs, int in_dtype /* 0 f32, 1 uint8, 2 bf16 */, const float* mean3, const float* std3, aim_bf16* A,
                  int B, int T, int H, int W, int p, int Kp, void* stream);
@@ -187,7 +192,8 @@ int64_t aim_embed_bwd_workspace_bytes(int B, int T, int N, int D);
 /* ------------------------------------------------------------------------------------------
  * Small reductions / casts used by the block's backward and the optimizer boundary.
  *   frame_sum : out[frame][d] = sum_tok w[tok] * x[frame*ntok + tok][d]   (x f32, w may be NULL)
- *   colsum    : out[c] += sum_m rs(m) * X[m][c]   (X bf16; rs as in the GEMM; fp32 atomics)
+ *   colsum    : out[c] += sum_m rs(m) * X[m][c]   (X bf16; rs as in the GEMM; two-stage ordered reduction through
+ *               the workspace, fp32 atomics only without one)
  *   cast      : f32 -> bf16 (optionally transposed [R,C] -> [C,R]) for weight staging
  *   scale_rows: y[r][c] = s[r] * x[r][c]  (f32 x -> bf16 y), used for lamda * crs_attn
  * ------------------------------------------------------------------------------------------ */

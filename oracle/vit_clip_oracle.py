@@ -182,12 +182,15 @@ def ref_block(x: Tensor, st: State, i: int, heads: int, num_frames: int, scale: 
 
     ``x``: ``[N, BT, D]``.  ``drop_mask``: optional ``[N,1,1]`` DropPath factor
     (timm semantics: ``bernoulli(keep)/keep`` over ``x.shape[0]``, i.e. per token
-    index; ``None`` = eval/identity).
+    index; ``None`` = eval/identity), or a PAIR of such factors: the block calls its
+    ``drop_path`` module twice (``:275`` and ``:286``) and every call draws a new mask.
     """
     pre = f"transformer.resblocks.{i}."
     n, bt, d = x.shape
     T = num_frames
-    dp = (lambda t: t) if drop_mask is None else (lambda t: t * drop_mask)
+    dm1, dm2 = drop_mask if isinstance(drop_mask, (tuple, list)) else (drop_mask, drop_mask)
+    dp1 = (lambda t: t) if dm1 is None else (lambda t: t * dm1.reshape(-1, 1, 1))
+    dp2 = (lambda t: t) if dm2 is None else (lambda t: t * dm2.reshape(-1, 1, 1))
     # temporal adaptation on the class tokens (:220-229)
     class_token = x[:1]                                           # 1, BT, D
     xt = class_token.reshape(1, bt // T, T, d).permute(2, 1, 0, 3).reshape(T, bt // T, d)
@@ -199,12 +202,12 @@ def ref_block(x: Tensor, st: State, i: int, heads: int, num_frames: int, scale: 
     ori_attn, ow = ref_attention(xl, xl, st, pre, heads, need_weights=True)
     crs_attn, cw = ref_attention(ln1(x), xt, st, pre, heads, need_weights=True)
     lamda = (cw / (cw + ow)).unsqueeze(0).unsqueeze(-1)
-    x = x + (1 - lamda) * ori_attn + dp(scale * ref_adapter(lamda * crs_attn, st, pre + "S_Adapter"))
+    x = x + (1 - lamda) * ori_attn + dp1(scale * ref_adapter(lamda * crs_attn, st, pre + "S_Adapter"))
     # joint adaptation (:285-286)
     xn = ref_layer_norm(x, st[pre + "ln_2.weight"], st[pre + "ln_2.bias"])
     h = F.linear(xn, st[pre + "mlp.c_fc.weight"], st[pre + "mlp.c_fc.bias"])
     h = F.linear(ref_quick_gelu(h), st[pre + "mlp.c_proj.weight"], st[pre + "mlp.c_proj.bias"])
-    x = x + h + dp(scale * ref_adapter(xn, st, pre + "MLP_Adapter"))
+    x = x + h + dp2(scale * ref_adapter(xn, st, pre + "MLP_Adapter"))
     if return_aux:
         return x, dict(ow=ow, cw=cw, lamda=lamda.reshape(-1), xt=xt.reshape(bt, d))
     return x
@@ -228,14 +231,15 @@ def ref_embed(imgs: Tensor, st: State, num_frames: int) -> Tensor:
 
 
 def ref_backbone(imgs: Tensor, st: State, heads: int, num_frames: int, scale: float = 0.5,
-                 layers: Optional[int] = None) -> Tensor:
-    """``ViT_CLIP.forward`` (``vit_clip.py:433-458``): ``[B,3,T,H,W] -> [B,D,T,1,1]`` (eval)."""
+                 layers: Optional[int] = None, drop_masks=None) -> Tensor:
+    """``ViT_CLIP.forward`` (``vit_clip.py:433-458``): ``[B,3,T,H,W] -> [B,D,T,1,1]``.
+    ``drop_masks``: None (eval) or one ``(mask1, mask2)`` pair (or None) per layer (train mode)."""
     B, _, T = imgs.shape[:3]
     if layers is None:
         layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
     x = ref_embed(imgs, st, num_frames)
     for i in range(layers):
-        x = ref_block(x, st, i, heads, num_frames, scale)
+        x = ref_block(x, st, i, heads, num_frames, scale, drop_mask=None if drop_masks is None else drop_masks[i])
     x = x.permute(1, 0, 2)
     x = ref_layer_norm(x, st["ln_post.weight"], st["ln_post.bias"])
     x = x[:, 0]
@@ -323,7 +327,8 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
               rnd: Rounding = FP32, drop_mask: Optional[Tensor] = None, return_aux: bool = False):
     """One block in the product's frame-major layout.
 
-    ``x``: ``[BT, N, D]`` fp32 residual stream.  ``drop_mask``: ``[N]`` or None.
+    ``x``: ``[BT, N, D]`` fp32 residual stream.  ``drop_mask``: ``[N]``, a pair of ``[N]``
+    (one per ``drop_path`` call, ``vit_clip.py:275,286``) or None.
     Algebra: one ``ln_1``; one fused QKV projection whose class
     rows also feed the temporal attention; the cross-attention over a single
     key collapses to ``out_proj(W_v xt + b_v)`` broadcast over tokens; ``ow``/``cw``
@@ -368,7 +373,9 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     ao = rnd(((rnd(pu) @ vh) / pu.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(BT, N, D))
     proj = _lin(ao, Wo, bo, rnd)                                    # fp32 accumulators
     sv = emu_adapter(rnd(lam[:, None] * crs), st, pre + "S_Adapter", rnd)   # [BT, D]
-    dm = 1.0 if drop_mask is None else drop_mask.reshape(1, N, 1)
+    d1, d2 = drop_mask if isinstance(drop_mask, (tuple, list)) else (drop_mask, drop_mask)
+    dm = 1.0 if d1 is None else d1.reshape(1, N, 1)
+    dm2 = 1.0 if d2 is None else d2.reshape(1, N, 1)
     x1 = x + (1 - lam)[:, None, None] * proj + dm * scale * sv[:, None, :]
     # --- MLP + MLP_Adapter --------------------------------------------------------
     xn = rnd(F.layer_norm(x1, (D,), st[pre + "ln_2.weight"], st[pre + "ln_2.bias"], 1e-5))
@@ -376,7 +383,7 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     h = rnd(ref_quick_gelu(hpre))
     mlp = _lin(h, st[pre + "mlp.c_proj.weight"], st[pre + "mlp.c_proj.bias"], rnd)
     ad = emu_adapter(xn, st, pre + "MLP_Adapter", rnd)
-    x2 = x1 + mlp + dm * scale * ad
+    x2 = x1 + mlp + dm2 * scale * ad
     if return_aux:
         # ow/cw are reported un-shifted only through their ratio; lam is the contract
         return x2, dict(lamda=lam, xt=xt, ow_shifted=ow, cw_shifted=cw, shift=m)
@@ -398,13 +405,13 @@ def emu_embed(imgs: Tensor, st: State, rnd: Rounding = FP32) -> Tensor:
 
 
 def emu_backbone(imgs: Tensor, st: State, heads: int, scale: float = 0.5,
-                 rnd: Rounding = FP32, layers: Optional[int] = None) -> Tensor:
+                 rnd: Rounding = FP32, layers: Optional[int] = None, drop_masks=None) -> Tensor:
     """Whole backbone in the product's dataflow: ``[B,3,T,H,W] -> [B,D,T,1,1]``."""
     B, _, T = imgs.shape[:3]
     if layers is None:
         layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
     x = emu_embed(imgs, st, rnd)
     for i in range(layers):
-        x = emu_block(x, st, i, heads, T, scale, rnd)
+        x = emu_block(x, st, i, heads, T, scale, rnd, drop_mask=None if drop_masks is None else drop_masks[i])
     c = F.layer_norm(x[:, 0], (x.shape[-1],), st["ln_post.weight"], st["ln_post.bias"], 1e-5)
     return c.reshape(B, T, -1).permute(0, 2, 1).unsqueeze(-1).unsqueeze(-1)

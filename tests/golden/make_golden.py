@@ -41,6 +41,8 @@ def load_reference():
     tl = stub("timm.models.layers")
 
     class DropPath(nn.Module):  # timm 0.5.4 semantics; only exercised in train mode
+        drawn = []              # every mask drawn (factor bernoulli/keep, shape [x.shape[0]]), in call order
+
         def __init__(self, drop_prob=0.):
             super().__init__()
             self.drop_prob = drop_prob
@@ -50,7 +52,9 @@ def load_reference():
                 return x
             keep = 1 - self.drop_prob
             mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-            return x * mask.div_(keep)
+            mask = mask.div_(keep)
+            DropPath.drawn.append(mask.reshape(-1).clone())
+            return x * mask
 
     tl.DropPath = DropPath
     tl.to_2tuple = lambda x: (x, x)
@@ -76,9 +80,9 @@ def randn(shape, seed):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float32)
 
 
-def build_ref(mod, res, T, patch, width, layers, heads, seed):
+def build_ref(mod, res, T, patch, width, layers, heads, seed, drop_path_rate=0.0):
     logging.getLogger("ref").setLevel(logging.ERROR)
-    m = mod.ViT_CLIP(res, T, patch, width, layers, heads, drop_path_rate=0.0, adapter_scale=0.5)
+    m = mod.ViT_CLIP(res, T, patch, width, layers, heads, drop_path_rate=drop_path_rate, adapter_scale=0.5)
     m.init_weights()  # applies the freeze policy
     st = O.synth_state_dict(O.backbone_param_shapes(res, T, patch, width, layers), seed=seed)
     missing = m.load_state_dict(st, strict=True)
@@ -134,6 +138,75 @@ def gen_block_real(mod, seed):
     np.savez_compressed(os.path.join(HERE, "block_real_T2.npz"), **npify(out))
 
 
+def _drawn():
+    import sys as _s
+    return _s.modules["timm.models.layers"].DropPath.drawn
+
+
+def _sample(t, k, seed):
+    """Fixture-sized view of a big tensor: k sampled elements + sum / sum of squares (fp64)."""
+    flat = t.detach().reshape(-1)
+    idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(seed))[:k]
+    return dict(idx=idx, val=flat[idx], sum=flat.double().sum(), sq=(flat.double() ** 2).sum())
+
+
+def gen_block_droppath(mod, T, seed, real=False):
+    """One block in TRAIN mode with DropPath active (vit_clip.py:112,275,286): the second block of a 2-layer
+    model (layer 0 has rate 0 = Identity, :297).  The masks the reference drew are stored with its outputs, so the
+    product and the oracle can be fed the same masks.  rate 0.5 at N = 5 / 0.3 at N = 197: zeros occur."""
+    if real:
+        D, H, N, B, res, rate = 768, 12, 197, 1, 224, 0.3
+    else:
+        D, H, N, B, res, rate = 128, 2, 5, 2, 32, 0.5
+    m, st = build_ref(mod, res, T, 16, D, 2, H, seed, drop_path_rate=rate)
+    blk = m.transformer.resblocks[1]
+    assert abs(blk.drop_path.drop_prob - rate) < 1e-6
+    blk.train()
+    x = randn((N, B * T, D), seed + 1).requires_grad_(True)
+    g = randn((N, B * T, D), seed + 2)
+    torch.manual_seed(seed + 9)
+    del _drawn()[:]
+    y = blk(x)
+    m1, m2 = _drawn()
+    assert (m1 == 0).any() and (m2 == 0).any() and not torch.equal(m1, m2), "pick another seed: masks must be non-trivial"
+    params = {n: p for n, p in blk.named_parameters() if p.requires_grad}
+    grads = torch.autograd.grad(y, [x] + list(params.values()), g)
+    out = dict(m1=m1, m2=m2, meta=np.array([D, H, N, B, T, seed]), rate=np.float64(rate))
+    if real:        # big tensors as samples (x and g are rebuilt from their seeds)
+        for k, t in (("y", y), ("dx", grads[0])):
+            out.update({f"{k}.{a}": b for a, b in _sample(t, 8192, seed + 3).items()})
+        for (n, _), gr in zip(params.items(), grads[1:]):
+            out.update({f"grad.{n}.{a}": b for a, b in _sample(gr, 2048, seed + 4).items()})
+        name = f"block_real_T{T}_droppath.npz"
+    else:
+        out.update(x=x, g=g, y=y, dx=grads[0])
+        for (n, _), gr in zip(params.items(), grads[1:]):
+            out["grad." + n] = gr
+        name = f"block_tiny_T{T}_droppath.npz"
+    np.savez_compressed(os.path.join(HERE, name), **npify(out))
+
+
+def gen_backbone_droppath(mod, T, seed):
+    """Whole tiny backbone (3 layers, rates linspace(0, .5, 3)) in TRAIN mode: output, all trainable gradients and
+    the 4 masks the reference drew (layers 1 and 2, two draws each)."""
+    D, H, L, B = 128, 2, 3, 2
+    m, st = build_ref(mod, 32, T, 16, D, L, H, seed, drop_path_rate=0.5)
+    m.train()
+    imgs = randn((B, 3, T, 32, 32), seed + 1)
+    g = randn((B, D, T, 1, 1), seed + 2)
+    torch.manual_seed(seed + 9)
+    del _drawn()[:]
+    y = m(imgs)
+    masks = list(_drawn())
+    assert len(masks) == 4 and any((k == 0).any() for k in masks)
+    params = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    grads = torch.autograd.grad(y, list(params.values()), g)
+    out = dict(imgs=imgs, g=g, y=y, meta=np.array([D, H, L, B, T, seed]), masks=torch.stack(masks))
+    for (n, _), gr in zip(params.items(), grads):
+        out["grad." + n] = gr
+    np.savez_compressed(os.path.join(HERE, f"backbone_tiny_T{T}_droppath.npz"), **npify(out))
+
+
 def gen_backbone_tiny(mod, T, seed):
     D, H, L, B = 128, 2, 2, 2
     m, st = build_ref(mod, 32, T, 16, D, L, H, seed)
@@ -173,12 +246,22 @@ def gen_cfg1(mod, seed):
 def main():
     torch.set_num_threads(8)
     mod = load_reference()
+    if "--droppath-only" in sys.argv:       # round 2 additions; the round-1 fixtures stay byte-identical
+        gen_block_droppath(mod, 2, 700)
+        gen_block_droppath(mod, 4, 800)
+        gen_block_droppath(mod, 2, 900, real=True)
+        gen_backbone_droppath(mod, 2, 1000)
+        return
     gen_block(mod, 2, 100)
     gen_block(mod, 4, 200)
     gen_block_real(mod, 300)
     gen_backbone_tiny(mod, 2, 400)
     gen_backbone_tiny(mod, 4, 500)
     gen_cfg1(mod, 600)
+    gen_block_droppath(mod, 2, 700)
+    gen_block_droppath(mod, 4, 800)
+    gen_block_droppath(mod, 2, 900, real=True)
+    gen_backbone_droppath(mod, 2, 1000)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -140,7 +140,9 @@ def test_recognizer_from_config_class_indices(golden_dir):
     z = _load(golden_dir, "backbone_tiny_T4.npz")
     D, H, L, B, T, seed = [int(v) for v in z["meta"]]
     cfg = aim_amd.Config.fromfile(os.path.join(os.path.dirname(__file__), "data", "vitclip_tiny_cfg.py"))
-    cfg.merge_from_dict({"model.backbone.num_frames": T})
+    # head dropout off (config override, as --cfg-options would): the train-mode loss is then deterministic and is
+    # pinned against the golden loss_cls at bf16 tolerance
+    cfg.merge_from_dict({"model.backbone.num_frames": T, "model.cls_head.dropout_ratio": 0.0})
     model = aim_amd.build_model(cfg.model).to(DEV).eval()
     st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, L), seed=seed)
     model.backbone.load_state_dict(st, strict=True)
@@ -168,7 +170,8 @@ def test_recognizer_from_config_class_indices(golden_dir):
     assert set(losses) == {"top1_acc", "top5_acc", "loss_cls"}
     loss, log_vars = model._parse_losses(losses)
     loss.backward()
-    assert abs(log_vars["loss_cls"] - float(z["loss_cls"])) < 1.5    # head dropout 0.5 is on in train mode
+    assert model.cls_head.dropout is None
+    assert abs(log_vars["loss_cls"] - float(z["loss_cls"])) < 2e-2, (log_vars["loss_cls"], float(z["loss_cls"]))
     assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
 
 
@@ -188,12 +191,12 @@ def test_droppath_mask_semantics():
 
 
 def test_full_size_properties():
-    """BASELINE config-2 shape per clip (ViT-B/16, 8 frames, 224^2) at a reduced clip count that the
-    CPU could not check in seconds: bitwise determinism of the forward, finite outputs, every trainable
+    """BASELINE configs[1] exactly (ViT-B/16, 8 frames, 224^2, 64 clips on one GPU), which the CPU oracle
+    cannot check in seconds: bitwise determinism of the forward, finite outputs, every trainable
     tensor gets a finite non-zero gradient, and one AdamW step changes only the trainable set."""
     m, st = _model(224, 8, 16, 768, 12, 12, 7)
     m.train()   # drop_path_rate 0 here, so train == eval numerically
-    B = 4
+    B = 64
     imgs = torch.randn((B, 3, 8, 224, 224), generator=torch.Generator().manual_seed(3)).to(DEV)
     with torch.no_grad():
         y1 = m(imgs)

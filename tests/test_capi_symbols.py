@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     for name in _declared():
         assert hasattr(lib, name), name
-    assert aim_amd.load_library().aim_version() == 1
+    from aim_amd.lib import ABI_VERSION
+    assert aim_amd.load_library().aim_version() == ABI_VERSION
 
 
 def test_missing_library_is_loud(monkeypatch):

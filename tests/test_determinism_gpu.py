@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _train(steps=3, B=8, frames=8):
+def _train(steps=3, B=64, frames=8):      # BASELINE configs[1]: 64 clips per GPU
     import bench
     from aim_amd.dist import build_optimizer
     dev = torch.device("cuda", 0)

@@ -145,3 +145,79 @@ def test_synth_weights_are_deterministic():
     a, b = O.synth_state_dict(sh, 7), O.synth_state_dict(sh, 7)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert not torch.equal(a["conv1.weight"], O.synth_state_dict(sh, 8)["conv1.weight"])
+
+
+# ---- DropPath active (train mode): fixtures hold the masks the REAL reference drew (vit_clip.py:112,275,286) ----
+def _sample_close(t, z, key, tol, rel=0.0):
+    flat = t.detach().reshape(-1)
+    _close(flat[z[key + ".idx"].long()], z[key + ".val"], tol, rel)
+    assert abs((flat.double() ** 2).sum().item() / max(float(z[key + ".sq"]), 1e-30) - 1) < 1e-4, key
+
+
+@pytest.mark.parametrize("T", [2, 4])
+def test_block_droppath_tiny(golden_dir, T):
+    """ref_block / emu_block with the reference's two masks (zeros included, m1 != m2): y, dX, 12 adapter grads."""
+    z = _load(golden_dir, f"block_tiny_T{T}_droppath.npz")
+    D, H, N, B, T_, seed = [int(v) for v in z["meta"]]
+    m1, m2 = z["m1"], z["m2"]
+    assert (m1 == 0).any() and (m2 == 0).any() and not torch.equal(m1, m2)
+    assert set(np.unique(m1.numpy())) <= {0.0, np.float32(1 / (1 - float(z["rate"])))}
+    st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, 2), seed=seed)
+    names = [k[5:] for k in z if k.startswith("grad.")]
+    assert len(names) == 12
+    full = ["transformer.resblocks.1." + n for n in names]
+    for n in full:
+        st[n].requires_grad_(True)
+    x = z["x"].clone().requires_grad_(True)
+    y = O.ref_block(x, st, 1, H, T, 0.5, drop_mask=(m1, m2))
+    _close(y, z["y"])
+    grads = torch.autograd.grad(y, [x] + [st[n] for n in full], z["g"])
+    _close(grads[0], z["dx"], 2e-5)
+    for n, g in zip(names, grads[1:]):
+        _close(g, z["grad." + n], 1e-5, rel=1e-5)
+    xe = z["x"].permute(1, 0, 2).contiguous().requires_grad_(True)
+    ye = O.emu_block(xe, st, 1, H, T, 0.5, O.FP32, drop_mask=(m1, m2))
+    _close(ye.permute(1, 0, 2), z["y"], 2e-5)
+    ge = torch.autograd.grad(ye, [xe] + [st[n] for n in full], z["g"].permute(1, 0, 2))
+    _close(ge[0].permute(1, 0, 2), z["dx"], 5e-5)
+    for n, g in zip(names, ge[1:]):
+        _close(g, z["grad." + n], 2e-5, rel=2e-5)
+    # the masks matter: a single shared mask gives a different block output
+    assert (O.ref_block(z["x"], st, 1, H, T, 0.5, drop_mask=m1).detach() - z["y"]).abs().max() > 1e-3
+
+
+def test_block_droppath_real_shape(golden_dir):
+    z = _load(golden_dir, "block_real_T2_droppath.npz")
+    D, H, N, B, T, seed = [int(v) for v in z["meta"]]
+    st = O.synth_state_dict(O.backbone_param_shapes(224, T, 16, D, 2), seed=seed)
+    names = sorted(k[5:-4] for k in z if k.startswith("grad.") and k.endswith(".idx"))
+    assert len(names) == 12
+    full = ["transformer.resblocks.1." + n for n in names]
+    for n in full:
+        st[n].requires_grad_(True)
+    x = _randn((N, B * T, D), seed + 1).requires_grad_(True)
+    g = _randn((N, B * T, D), seed + 2)
+    y = O.ref_block(x, st, 1, H, T, 0.5, drop_mask=(z["m1"], z["m2"]))
+    _sample_close(y, z, "y", 2e-5)
+    grads = torch.autograd.grad(y, [x] + [st[n] for n in full], g)
+    _sample_close(grads[0], z, "dx", 2e-5)
+    for n, gr in zip(names, grads[1:]):
+        _sample_close(gr, z, "grad." + n, 2e-5, rel=1e-4)
+
+
+def test_backbone_droppath_tiny(golden_dir):
+    z = _load(golden_dir, "backbone_tiny_T2_droppath.npz")
+    D, H, L, B, T, seed = [int(v) for v in z["meta"]]
+    st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, L), seed=seed)
+    names = O.trainable_names(st)
+    mk = z["masks"]
+    masks = [None, (mk[0], mk[1]), (mk[2], mk[3])]      # layer 0 has rate 0 (vit_clip.py:297)
+    for fn in (lambda: O.ref_backbone(z["imgs"], st, H, T, drop_masks=masks),
+               lambda: O.emu_backbone(z["imgs"], st, H, drop_masks=masks)):
+        for n in names:
+            st[n] = st[n].detach().requires_grad_(True)
+        y = fn()
+        _close(y, z["y"], 2e-5)
+        grads = torch.autograd.grad(y, [st[n] for n in names], z["g"])
+        for n, g in zip(names, grads):
+            _close(g, z["grad." + n], 2e-5, rel=5e-5)

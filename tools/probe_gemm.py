@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-tile timeline of the persistent 256x256 GEMM (aim_gemm_probe): K-loop vs epilogue time per tile."""
+"""Per-tile timeline of the persistent 256x256 GEMM (aim_gemm_args.probe): K-loop vs epilogue time per tile."""
 import os
 import sys
 import numpy as np
@@ -33,12 +33,9 @@ def run(name, N, K, epi):
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     cap = tiles + 512
     buf = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
-    lib = load_library()
     torch.cuda.synchronize()
-    lib.aim_gemm_probe(buf.data_ptr(), cap)
-    ops.gemm(a, w, epi, out, **kw)
+    ops.gemm(a, w, epi, out, probe=buf, **kw)
     torch.cuda.synchronize()
-    lib.aim_gemm_probe(None, 0)
     p = buf.cpu().numpy()
     if os.environ.get("STAMPS"):        # diagnostic build only (-DAIM_X_STAMPS): phase stamps of workgroup 0, waves 0 and 4
         raw = p[cap - 32:].reshape(-1)
