@@ -21,12 +21,12 @@ def run_smoke():
         st[n] = st[n].detach().requires_grad_(True)
     y_ref = O.emu_backbone(imgs, st, H, rnd=O.BF16)
     grads = torch.autograd.grad(y_ref, [st[n] for n in names], g)
-    # same bars as tests/test_backbone_gpu.py: relative L2 <= 3e-3, max-abs within 3 bf16 ulps of O(1) outputs
+    # same bars as tests/test_backbone_gpu.py: relative L2 <= 3e-3, max-abs within 3 bf16 ulps of O(1) outputs, gradients <= 2.5e-2
     err = (y.detach().cpu() - y_ref.detach()).abs().max().item()
     rel = ((y.detach().cpu() - y_ref.detach()).norm() / y_ref.detach().norm()).item()
     assert rel < 3e-3 and err < 1.2e-2, f"smoke forward mismatch: rel {rel} max {err}"
     got = dict(m.named_parameters())
     for n, gr in zip(names, grads):
         e = ((got[n].grad.cpu() - gr).norm() / (gr.norm() + 1e-30)).item()
-        assert e < 6e-2, f"smoke grad mismatch {n}: {e}"
+        assert e < 2.5e-2, f"smoke grad mismatch {n}: {e}"
     print(f"smoke ok: fwd rel err {rel:.2e}, max err {err:.2e}")

@@ -71,7 +71,7 @@ def test_tiny_backbone_forward_backward(golden_dir, T):
         assert got[n].shape == ref.shape
         e = _relerr(got[n], ref)
         worst = max(worst, e)
-        assert e < 6e-2, (n, e)
+        assert e < 2.5e-2, (n, e)      # measured <= 1.4e-2 (gpurun_out/parity_r02.jsonl)
     # frozen tensors received no gradient
     assert all(p.grad is None for n, p in m.named_parameters() if not p.requires_grad)
 
@@ -109,11 +109,11 @@ def test_block_against_reference_fixture(golden_dir, T):
     g = z["g"].permute(1, 0, 2).contiguous().reshape(B * T * N, D).to(DEV)
     dx = bb._block_backward(g.to(torch.bfloat16), c, fz, adp, grads, B, T, N, H)
     dx_ref = z["dx"].permute(1, 0, 2).reshape(B * T * N, D)
-    assert _relerr(dx, dx_ref) < 3e-2, _relerr(dx, dx_ref)
+    assert _relerr(dx, dx_ref) < 1.5e-2, _relerr(dx, dx_ref)       # measured 5e-3
     for a in bb._ADAPTERS:
         for leaf in bb._ADAPTER_LEAVES:
             e = _relerr(grads[a][leaf], z[f"grad.{a}.{leaf}"])
-            assert e < 5e-2, (a, leaf, e)
+            assert e < 2.5e-2, (a, leaf, e)                              # measured <= 1.1e-2
 
 
 def test_cfg1_shape_forward(golden_dir):
@@ -239,7 +239,7 @@ def test_vit_l14_shape_matches_oracle():
     got = dict(m.named_parameters())
     for n, gr in zip(names, grads):
         e = _relerr(got[n].grad, gr)
-        assert e < 6e-2, (n, e)
+        assert e < 2.5e-2, (n, e)
 
 
 def test_uint8_input_with_fused_gpu_normalize(golden_dir):

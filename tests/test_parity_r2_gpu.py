@@ -96,10 +96,15 @@ def _emu_block_grads(st, layer, x_nbd, g_nbd, H, T, m1, m2):
     return ye.detach().permute(1, 0, 2), gr[0].permute(1, 0, 2), dict(zip(names, gr[1:]))
 
 
-# per-tensor gradient bound vs the same-rounding-point oracle's autograd: the product rounds the residual-stream
-# gradient to bf16 once per LayerNorm and every dgrad operand to bf16 (2^-9 relative each), the oracle's
-# straight-through autograd does not; the relative L2 error of a tensor stays in the few-1e-3 class
-GRAD_EMU_BOUND = 1e-2
+# Per-tensor gradient bounds (relative L2) vs the same-rounding-point oracle's autograd.  The product rounds the
+# residual-stream gradient to bf16 once per LayerNorm backward (twice per block) and every dgrad operand to bf16
+# (2^-9 relative each); the oracle's straight-through autograd keeps fp32.  One block: measured 3e-3 .. 7e-3, bound 1e-2.
+# Through L blocks the roundings add in quadrature (~ sqrt(2 L) * 2^-9): measured median over all trainable tensors
+# 3.6e-3 / 7.8e-3 / 9.8e-3 at 2 / 12 / 24 layers; the worst tensor is always one on the class-token path of a LOW
+# layer (T_/S_Adapter: its gradient is a sum over B*T rows only -- 2 to 4 rows in these one-clip cases -- so nothing
+# averages the rounding out): 1.2e-2 / 3.2e-2 / 2.8e-2.  Bounds leave ~1.5x.
+GRAD_EMU_BOUND = 1e-2                                    # single block
+GRAD_EMU_DEPTH = {2: (2e-2, 8e-3), 12: (5e-2, 1.5e-2), 24: (5e-2, 1.5e-2)}      # layers -> (worst tensor, median)
 GRAD_REF_BOUND = 2.5e-2      # vs the real reference's fp32 autograd: adds the forward's bf16 error
 
 
@@ -142,7 +147,11 @@ def test_block_droppath_real_shape(golden_dir):
              grad_ref=max(samp(grads[n], "grad." + n) for n in ge),
              per_tensor_emu={n: _rel(grads[n], ge[n]) for n in ge})
     _record("block_droppath_real_T2", **e)
-    assert e["y_emu_rel"] < 1e-3 and e["y_emu_max"] < 1.6e-2, e
+    # At K = 768 / 3072 two implementations that differ only in fp32 summation order disagree on ~1 % of the bf16
+    # rounding decisions of every stored intermediate, and each flipped element (one bf16 ulp = 2^-8 relative) perturbs
+    # the next stage: the chain settles at a relative L2 distance of ~1e-3 whatever the implementation (DESIGN.md
+    # section 5, "noise floor").  Measured 1.09e-3 here (tiny shapes: 1e-7 .. 2e-4); the bound leaves 2x.
+    assert e["y_emu_rel"] < 2e-3 and e["y_emu_max"] < 1.6e-2, e
     assert e["y_ref_rel"] < 8e-3, e
     assert e["dx_emu"] < GRAD_EMU_BOUND and e["dx_ref"] < GRAD_REF_BOUND, e
     assert e["grad_emu"] < GRAD_EMU_BOUND and e["grad_ref"] < GRAD_REF_BOUND, e
@@ -181,7 +190,7 @@ def test_backbone_droppath_tiny(golden_dir, monkeypatch):
              grad_emu=max(_rel(got[n], ge[n]) for n in names), grad_ref=max(_rel(got[n], z["grad." + n]) for n in names))
     _record("backbone_droppath_tiny_T2", **e)
     assert e["y_emu_rel"] < 3e-3 and e["y_emu_max"] < 1.2e-2 and e["y_ref_rel"] < 1.5e-2, e
-    assert e["grad_emu"] < GRAD_EMU_BOUND and e["grad_ref"] < GRAD_REF_BOUND, e
+    assert e["grad_emu"] < GRAD_EMU_DEPTH[2][0] and e["grad_ref"] < GRAD_REF_BOUND, e
 
 
 # ---- errors by depth -------------------------------------------------------------------------------------------
@@ -210,7 +219,8 @@ def _depth_case(tag, res, T, patch, D, L, H, seed, B, with_grads, y_rel_bound, y
     _record(tag, layers=L, **e)
     assert e["y_emu_rel"] < y_rel_bound and e["y_emu_max"] < y_max_bound, e
     if with_grads:
-        assert e["grad_emu_worst"] < GRAD_EMU_BOUND, e
+        worst_b, med_b = GRAD_EMU_DEPTH[L]
+        assert e["grad_emu_worst"] < worst_b and e["grad_emu_median"] < med_b, e
     return e
 
 
@@ -267,7 +277,7 @@ def test_cfg3_shape_train_step_properties():
                 if p.requires_grad:
                     assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)), losses
     changed = sorted(n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
