@@ -349,6 +349,16 @@ class _Fork:
         return done
 
     @staticmethod
+    def streams(dev):
+        """The streams of this device that may carry gradient-producing kernels (current, side, detached)."""
+        key = (dev.type, dev.index)
+        out = [torch.cuda.current_stream(dev)]
+        for table in (_SIDE, _DETACHED):
+            if key in table:
+                out.append(table[key])
+        return out
+
+    @staticmethod
     def join_detached(dev):
         """The current stream waits for everything queued by ``run_detached``."""
         w = _DETACHED.get((dev.type, dev.index))
@@ -729,9 +739,16 @@ class _BackboneFn(torch.autograd.Function):
         ops.layernorm_bwd(dy, s["xL"], s["gw"], s["meanp"], s["rstdp"], BT, D, lddy=D, ldx=N * D, lddx=N * D,
                           dx_bf16=dxb, dgamma=dgw, dbeta=dgb)
         keep: list = []        # tensors the detached weight-gradient stream still reads; dropped after join_detached
+        hook = model.grad_ready_hook
         for i in reversed(range(L)):
             dxb = _block_backward(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
             s["ctxs"][i] = None
+            if hook is not None:
+                # every kernel that accumulates into the gradients of layers >= i has been QUEUED (adapter weight
+                # gradients on the detached stream): the data-parallel optimizer may start reducing that slice of the
+                # flat gradient buffer behind events on these streams, while the backward of layers < i still runs
+                k0 = 3 + i * 12
+                hook(i, all(in_place[k0:k0 + 12]), _Fork.streams(dev))
         dtmp = buf(0)
         ops.embed_bwd(dxb, s["tok"], frozen["cls"], frozen["pos"], s["tmp"], frozen["gpre"], s["mean0"], s["rstd0"],
                       dtmp.view(T, D), B, T, N, D)
@@ -778,6 +795,7 @@ class ViT_CLIP(nn.Module):
         self._frozen_cache = None
         self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
+        self.grad_ready_hook = None                 # fn(layer, in_place, streams): set by dist.FlatAdamW (overlapped all-reduce)
         self._cast_table = None
 
     # ---- reference API ------------------------------------------------------------------------

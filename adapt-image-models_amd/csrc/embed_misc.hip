@@ -405,12 +405,12 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const aim_cast_desc* __
 // AdamW (decoupled weight decay) on flat fp32 buffers, torch.optim.AdamW semantics.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s, float gs) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 3 < n) {
         f32x4 pp = *(f32x4*)(p + i), mm = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
-        const f32x4 gg = *(const f32x4*)(g + i);
+        const f32x4 gg = *(const f32x4*)(g + i) * gs;       // gs = 1 / world: the SUM all-reduce becomes the mean here
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             pp[e] *= 1.0f - lr * wd;
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     } else {
         for (long long j = i; j < n; ++j) {
             float pp = p[j] * (1.0f - lr * wd);
-            const float mm = b1 * m[j] + (1.0f - b1) * g[j], vv = b2 * v[j] + (1.0f - b2) * g[j] * g[j];
+            const float gj = g[j] * gs;
+            const float mm = b1 * m[j] + (1.0f - b1) * gj, vv = b2 * v[j] + (1.0f - b2) * gj * gj;
             pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2s + eps);
             p[j] = pp; m[j] = mm; v[j] = vv;
         }
@@ -434,11 +435,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }  // namespace
 
 extern "C" int aim_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, void* stream) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
     AIM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     AIM_CHECK_LAUNCH("aim_adamw_flat");
     return 0;
 }

@@ -2,11 +2,16 @@
 
 The reference wraps the recognizer in torch DDP (mmaction/apis/train.py:106-110), which buckets the
 ``requires_grad`` parameters (10 966 672 elements for ViT-B/16, T=8, 400 classes) into 25 MB NCCL
-calls and all-reduces on every micro-step.  Here all trainable gradients live in ONE contiguous fp32
-buffer (``param.grad`` are views into it), so a step is a single RCCL all-reduce over xGMI; with
-gradient accumulation only the boundary micro-step communicates.  The frozen 86 M backbone weights
-are never communicated after the initial broadcast.
+calls that fire during backward, on every micro-step.  Here all trainable gradients live in ONE contiguous fp32
+buffer (``param.grad`` are views into it) and a step reduces it in at most three RCCL calls over xGMI: the slices of the
+upper two thirds of the layers start on a communication stream as soon as the backward has queued their last
+producers (``ViT_CLIP.grad_ready_hook``), overlapped with the backward of the lower layers; the rest follows when
+backward returns.  The collective is a SUM; the 1/world of DDP's mean is folded into the AdamW kernel
+(``aim_adamw_flat(grad_scale=)``), so there is no separate pass over the buffer.  With gradient accumulation only the
+boundary micro-step communicates (``FlatAdamW.no_sync()``).  The frozen 86 M backbone weights are never communicated
+after the initial broadcast.
 """
+import contextlib
 import os
 from typing import Iterable, List
 
@@ -121,6 +126,69 @@ class FlatAdamW:
             grp["range"][1] = off
         self.step_count = 0
         self.numel = total
+        # overlapped reduction state (see attach_backbone)
+        self._buckets = []           # [(first_layer, a, b)]: flat range [a, b) is complete once `first_layer`'s backward is queued
+        self._works = []
+        self._reduced = []           # ranges already handed to the collective in this step
+        self._sync = True
+        self._comm = None
+        self.early_launches = 0      # diagnostics: collectives started from inside backward
+
+    # ---- overlapped all-reduce ---------------------------------------------------------------------------------
+    @staticmethod
+    def _world():
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def attach_backbone(self, backbone, prefix_of=None, n_buckets: int = 3):
+        """Plan early buckets over the flat buffer from the backbone's layer order and install its
+        ``grad_ready_hook``.  Layers [L*(k-1)/n, L*k/n) form bucket k; bucket k (k >= 1) fires when the backward of its
+        lowest layer has been queued, bucket 0 (lowest layers + everything else) after backward.  A bucket is used only
+        if its parameters occupy ONE contiguous range of the flat buffer holding nothing else."""
+        blocks = list(backbone.transformer.resblocks)
+        L = len(blocks)
+        pos = {id(p): (off, n) for p, off, n in self._views}
+        pad = lambda n: (n + 3) // 4 * 4
+        self._buckets = []
+        for k in range(n_buckets - 1, 0, -1):
+            lo, hi = L * k // n_buckets, L * (k + 1) // n_buckets
+            ps = [p for blk in blocks[lo:hi] for p in blk.parameters() if p.requires_grad]
+            if not ps or any(id(p) not in pos for p in ps):
+                continue
+            a = min(pos[id(p)][0] for p in ps)
+            b = max(pos[id(p)][0] + pad(pos[id(p)][1]) for p in ps)
+            if b - a == sum(pad(pos[id(p)][1]) for p in ps):
+                self._buckets.append((lo, a, b))
+        backbone.grad_ready_hook = self._on_layer_queued
+        return self._buckets
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: micro-steps inside do not communicate (DDP.no_sync semantics)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def _on_layer_queued(self, layer: int, in_place: bool, streams):
+        if not self._sync or self._world() == 1 or not in_place:
+            return
+        for lo, a, b in self._buckets:
+            if lo == layer and (a, b) not in self._reduced:
+                self._launch(a, b, streams)
+
+    def _launch(self, a: int, b: int, streams):
+        dev = self.flat_g.device
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=dev)
+        for st in streams:                       # behind everything queued so far on the producing streams
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._comm.wait_event(ev)
+        with torch.cuda.stream(self._comm):
+            self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+        self._reduced.append((a, b))
+        self.early_launches += 1
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
@@ -129,26 +197,78 @@ class FlatAdamW:
                 p.grad = self.flat_g[off:off + n].view_as(p)
 
     def all_reduce_grads(self):
-        """Mean of the flat gradient over ranks: ONE RCCL all-reduce per step."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g)                       # SUM over xGMI (RCCL) ...
-            self.flat_g.mul_(1.0 / dist.get_world_size())      # ... then the mean, one 44 MB elementwise pass
+        """Finish the step's gradient reduction (SUM over ranks; the mean's 1/world is applied inside ``step``): reduce
+        whatever the early buckets did not cover -- everything, when no backbone is attached -- and make the current
+        stream wait for all of it."""
+        if self._world() == 1 or not self._sync:
+            return
+        todo, cur = [], 0
+        for a, b in sorted(self._reduced):
+            if a > cur:
+                todo.append((cur, a))
+            cur = max(cur, b)
+        if cur < self.numel:
+            todo.append((cur, self.numel))
+        for a, b in todo:
+            self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+        for w in self._works:
+            w.wait()                                    # stream-ordered on GPU backends: no host sync
+        self._works, self._reduced = [], []
 
     def step(self):
         self.step_count += 1
+        gs = 1.0 / self._world()                        # SUM all-reduce -> mean, inside the optimizer kernel
         for grp in self.param_groups:
             a, b = grp["range"]
             if b > a:
                 self._ops.adamw_flat(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], grp["lr"],
-                                     grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self.step_count)
+                                     grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self.step_count,
+                                     grad_scale=gs)
 
     def state_dict(self):
-        return dict(step=self.step_count, m=self.flat_m.clone(), v=self.flat_v.clone(),
-                    groups=[dict(lr=g["lr"], weight_decay=g["weight_decay"], range=list(g["range"])) for g in self.param_groups])
+        """torch.optim-shaped: ``state`` = per-parameter {step, exp_avg, exp_avg_sq} keyed by the parameter's index in
+        ``param_groups`` order, ``param_groups`` = hyper-parameters + index lists -- so a checkpoint written here loads
+        into ``torch.optim.AdamW`` over the same parameter order and vice versa (mmcv's checkpoint hook stores
+        ``optimizer.state_dict()`` as is: mmcv_custom/runner/checkpoint.py:39-80)."""
+        pos = {id(p): (off, n) for p, off, n in self._views}
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                off, n = pos[id(p)]
+                if self.step_count > 0:
+                    state[idx] = dict(step=torch.tensor(float(self.step_count)),
+                                      exp_avg=self.flat_m[off:off + n].view_as(p).clone(),
+                                      exp_avg_sq=self.flat_v[off:off + n].view_as(p).clone())
+                ids.append(idx)
+                idx += 1
+            groups.append(dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
+                               amsgrad=False, params=ids))
+        return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.flat_m.copy_(sd["m"]); self.flat_v.copy_(sd["v"])
+        pos = {id(p): (off, n) for p, off, n in self._views}
+        flat = [p for g in self.param_groups for p in g["params"]]
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            if len(sg["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k in ("lr", "weight_decay", "eps"):
+                if k in sg:
+                    g[k] = float(sg[k])
+            if "betas" in sg:
+                g["betas"] = tuple(sg["betas"])
+        steps = set()
+        for idx, st in sd["state"].items():
+            p = flat[int(idx)]
+            off, n = pos[id(p)]
+            self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW keeps one step count for all parameters")
+        self.step_count = steps.pop() if steps else 0
 
 
 def shard_indices(n: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True):
@@ -193,6 +313,8 @@ def build_optimizer(model: torch.nn.Module, cfg: dict):
         for m in model.modules():            # the backbone may now add its gradients straight into the flat buffer
             if hasattr(m, "grad_in_place"):
                 m.grad_in_place = True
+                if hasattr(m, "transformer"):
+                    opt.attach_backbone(m)        # early buckets of the all-reduce start during backward
         return opt
     opt_cls = getattr(torch.optim, typ)
     return opt_cls(groups, **cfg)

@@ -64,7 +64,10 @@ SIGNATURES = {
     "aim_cast_bf16": [P, P, I, I, I, I, P],
     "aim_scale_rows": [P, P, P, P, I, I, P],
     "aim_add_rows_bf16": [P, L, P, I, I, P],
-    "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "aim_adamw_flat": [P, P, P, P, L, F, F, F, F, F, I, F, P],
+    "aim_head_fwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "aim_head_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "aim_ce_topk": [P, P, P, P, P, I, I, I, P],
     "aim_cast_multi": [P, I, P],
 }
 

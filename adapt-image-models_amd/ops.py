@@ -285,11 +285,53 @@ def add_rows(dst, dst_row_stride: int, src):
           "aim_add_rows_bf16")
 
 
-def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+def adamw_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale: float = 1.0):
     for n_, t_ in (("p", p), ("g", g), ("m", m), ("v", v)):
         _chk(t_, F32, n_)
     check(load_library().aim_adamw_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
-                                        beta2, eps, weight_decay, step, _stream()), "aim_adamw_flat")
+                                        beta2, eps, weight_decay, step, grad_scale, _stream()), "aim_adamw_flat")
+
+
+def head_fwd(feat, drop, W, bias):
+    """feat [B, T, D] f32 -> (pooled [B, D], score [B, C]) ; drop [B, D] factor table or None."""
+    _chk(feat, F32, "feat"); _chk(drop, F32, "drop"); _chk(W, F32, "W"); _chk(bias, F32, "bias")
+    B, T, D = feat.shape
+    C = W.shape[0]
+    assert feat.is_contiguous() and W.is_contiguous() and W.shape[1] == D
+    pooled = torch.empty((B, D), dtype=F32, device=feat.device)
+    score = torch.empty((B, C), dtype=F32, device=feat.device)
+    check(load_library().aim_head_fwd(feat.data_ptr(), _p(drop), W.data_ptr(), _p(bias), pooled.data_ptr(),
+                                      score.data_ptr(), B, T, D, C, _stream()), "aim_head_fwd")
+    return pooled, score
+
+
+def head_bwd(dscore, pooled, drop, W, T, need_dfeat=True):
+    """-> (dW [C, D], db [C], dfeat [B, T, D] or None)."""
+    _chk(dscore, F32, "dscore"); _chk(pooled, F32, "pooled"); _chk(drop, F32, "drop"); _chk(W, F32, "W")
+    B, C = dscore.shape
+    D = W.shape[1]
+    assert dscore.is_contiguous() and pooled.is_contiguous()
+    dW = torch.zeros((C, D), dtype=F32, device=W.device)
+    db = torch.zeros((C,), dtype=F32, device=W.device)
+    dfeat = torch.empty((B, T, D), dtype=F32, device=W.device) if need_dfeat else None
+    check(load_library().aim_head_bwd(dscore.data_ptr(), pooled.data_ptr(), _p(drop), W.data_ptr(), dW.data_ptr(),
+                                      db.data_ptr(), _p(dfeat), B, T, D, C, _stream()), "aim_head_bwd")
+    return dW, db, dfeat
+
+
+def ce_topk(score, label, k2: int = 5, need_grad: bool = True):
+    """-> (out3 = [mean CE, top-1, top-k2] f32, dscore [B, C] = (softmax - onehot) / B or None)."""
+    _chk(score, F32, "score")
+    if label.dtype != torch.int64 or not label.is_cuda:
+        raise TypeError("ce_topk: label must be an int64 GPU tensor")
+    B, C = score.shape
+    assert score.is_contiguous() and label.numel() == B
+    dscore = torch.empty_like(score) if need_grad else None
+    ws = torch.empty((B, 3), dtype=F32, device=score.device)
+    out3 = torch.empty((3,), dtype=F32, device=score.device)
+    check(load_library().aim_ce_topk(score.data_ptr(), label.data_ptr(), _p(dscore), ws.data_ptr(), out3.data_ptr(), B, C,
+                                     k2, _stream()), "aim_ce_topk")
+    return out3, dscore
 
 
 class CastTable:

@@ -7,10 +7,14 @@
 * ``GPUNormalize`` / ``register_module_hooks`` -- mmaction/utils/module_hooks.py:8-87 (fused into the
   patch-embedding kernel when the hooked module is this package's ``ViT_CLIP``).
 
-These are thin plain-PyTorch host modules (a few hundred kFLOP per step); the hot path is the
-backbone.  Differences from the reference that are deliberate: top-k accuracy is computed on the
-device (no ``.cpu().numpy()`` sync per iteration, heads/base.py:90) and ``_parse_losses`` reduces the
-log scalars in ONE all-reduce instead of four (recognizers/base.py:237-242).
+These are thin host modules; the hot path is the backbone.  On GPU tensors the K400 training tail runs on
+HIP kernels of libaim_hip.so: ``aim_head_fwd/bwd`` (avg-pool over frames + dropout + fc_cls)
+and ``aim_ce_topk`` (hard-label cross-entropy + top-1/top-5 in one launch, no ``.cpu().numpy()`` sync per iteration,
+heads/base.py:90).  ``_parse_losses`` reduces the log scalars in ONE all-reduce instead of four
+(recognizers/base.py:237-242) and hands them back as lazily materialised floats (no host sync until a logger reads
+them).  Plain PyTorch ops remain for what the K400 configs never use on this path (soft labels, class weights,
+multi_class heads, non-average pooling) and for CPU tensors in host-logic tests; if the HIP library is missing, a GPU
+call raises ``LibraryNotBuilt`` -- it never falls back.
 """
 from collections import OrderedDict
 
@@ -23,6 +27,57 @@ import torch.nn.functional as F
 from .registry import HEADS, LOSSES, RECOGNIZERS, Registry, build_backbone, build_head, build_loss
 
 MODULE_HOOKS = Registry("module_hooks")
+
+
+class LazyLogVars(OrderedDict):
+    """``log_vars`` of ``_parse_losses``: an OrderedDict of Python floats that is filled in on FIRST READ.
+
+    The reference calls ``.item()`` on every log variable in every iteration (recognizers/base.py:242): four host
+    syncs per step.  Here the packed scalars start an asynchronous device-to-host copy into pinned memory when they
+    are produced; whoever reads a value first (a logger hook every N iterations, a test) waits for that copy once."""
+
+    def __init__(self, keys, packed: torch.Tensor):
+        super().__init__((k, None) for k in keys)
+        self._keys = list(keys)
+        if packed.is_cuda:
+            self._host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            self._host.copy_(packed, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = packed, None
+        self._done = False
+
+    def _materialise(self):
+        if not self._done:
+            self._done = True
+            if self._event is not None:
+                self._event.synchronize()
+            for k, v in zip(self._keys, self._host.tolist()):
+                OrderedDict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        self._materialise()
+        return OrderedDict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._materialise()
+        return OrderedDict.get(self, k, default)
+
+    def items(self):
+        self._materialise()
+        return OrderedDict.items(self)
+
+    def values(self):
+        self._materialise()
+        return OrderedDict.values(self)
+
+    def __iter__(self):
+        return OrderedDict.__iter__(self)
+
+    def __repr__(self):
+        self._materialise()
+        return "LazyLogVars(%s)" % dict(OrderedDict.items(self))
 
 
 def top_k_accuracy(scores, labels, topk=(1,)):
@@ -47,6 +102,42 @@ def top_k_accuracy_device(cls_score: torch.Tensor, labels: torch.Tensor, topk=(1
     return [(rank < min(k, s.shape[1])).float().mean() for k in topk]
 
 
+class _HeadFn(torch.autograd.Function):
+    """avg-pool over frames -> dropout factors -> fc_cls on ``aim_head_fwd`` / ``aim_head_bwd``."""
+
+    @staticmethod
+    def forward(ctx, feat, drop, W, b):
+        from . import ops
+        Wc = W.detach().float().contiguous()
+        pooled, score = ops.head_fwd(feat.detach().float().contiguous(), drop, Wc, None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(pooled, Wc)
+        ctx.drop, ctx.T, ctx.has_bias = drop, feat.shape[1], b is not None
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        from . import ops
+        pooled, Wc = ctx.saved_tensors
+        dW, db, dfeat = ops.head_bwd(dscore.float().contiguous(), pooled, ctx.drop, Wc, ctx.T, need_dfeat=ctx.needs_input_grad[0])
+        return dfeat, None, dW, (db if ctx.has_bias else None)
+
+
+class _CETopkFn(torch.autograd.Function):
+    """[mean CE, top-1, top-5] from ``aim_ce_topk``; only the CE slot carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, score, label):
+        from . import ops
+        out3, dscore = ops.ce_topk(score.detach().float().contiguous(), label.reshape(-1).contiguous(), 5, need_grad=True)
+        ctx.save_for_backward(dscore)
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        (dscore,) = ctx.saved_tensors
+        return dscore * g3[0], None
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
     def __init__(self, loss_weight=1.0, class_weight=None):
@@ -69,6 +160,8 @@ class CrossEntropyLoss(nn.Module):
         if self.class_weight is not None:
             assert 'weight' not in kwargs, "The key 'weight' already exists."
             kwargs['weight'] = self.class_weight.to(cls_score.device)
+        if cls_score.is_cuda and not kwargs and cls_score.dim() == 2 and label.dtype == torch.int64:
+            return _CETopkFn.apply(cls_score, label)[0]          # hard labels on the GPU: aim_ce_topk
         return F.cross_entropy(cls_score, label, **kwargs)
 
     def forward(self, *args, **kwargs):
@@ -95,6 +188,16 @@ class I3DHead(nn.Module):
         nn.init.constant_(self.fc_cls.bias, 0)
 
     def forward(self, x):
+        if x.is_cuda and self.avg_pool is not None and x.dim() == 5:
+            # [B, C, T, H, W] -> [B, T*H*W, C]; the backbone's [B, D, T, 1, 1] output is a view of a frame-major
+            # [B, T, D] buffer, so this is free.  Dropout is a caller-drawn factor table (same semantics as nn.Dropout
+            # on the pooled [B, C] features: bernoulli(1 - p) / (1 - p)).
+            feat = x.flatten(2).permute(0, 2, 1).contiguous()
+            drop = None
+            if self.dropout is not None and self.training:
+                keep = 1.0 - self.dropout_ratio
+                drop = torch.empty((feat.shape[0], feat.shape[2]), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+            return _HeadFn.apply(feat, drop, self.fc_cls.weight, self.fc_cls.bias)
         if self.avg_pool is not None:
             x = self.avg_pool(x)
         if self.dropout is not None:
@@ -108,6 +211,13 @@ class I3DHead(nn.Module):
             labels = labels.unsqueeze(0)
         elif labels.dim() == 1 and labels.size()[0] == self.num_classes and cls_score.size()[0] == 1:
             labels = labels.unsqueeze(0)
+        if (not self.multi_class and cls_score.size() != labels.size() and cls_score.is_cuda and not kwargs
+                and isinstance(self.loss_cls, CrossEntropyLoss) and self.loss_cls.class_weight is None
+                and cls_score.dim() == 2 and labels.dtype == torch.int64):
+            out3 = _CETopkFn.apply(cls_score, labels)        # CE + top-1/top-5 in one launch, nothing leaves the GPU
+            losses['top1_acc'], losses['top5_acc'] = out3[1].detach(), out3[2].detach()
+            losses['loss_cls'] = out3[0] * self.loss_cls.loss_weight
+            return losses
         if not self.multi_class and cls_score.size() != labels.size():
             top1, top5 = top_k_accuracy_device(cls_score, labels, (1, 5))
             losses['top1_acc'], losses['top5_acc'] = top1, top5
@@ -227,9 +337,7 @@ class Recognizer3D(nn.Module):
         packed = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(packed.div_(dist.get_world_size()))
-        for (k, _), v in zip(list(log_vars.items()), packed.tolist()):
-            log_vars[k] = v
-        return loss, log_vars
+        return loss, LazyLogVars(list(log_vars.keys()), packed)
 
     def forward(self, imgs, label=None, return_loss=True, **kwargs):
         if kwargs.get('gradcam', False):

@@ -223,9 +223,31 @@ int aim_cast_multi(const aim_cast_desc* table_dev, int n, void* stream);
  * per parameter group -- the reference steps 149 small tensors through mmcv's optimizer hook
  * (mmaction/utils/optimizer.py:22-33, configs/recognition/vit/vitclip_base_k400.py:96-102).
  * `step` is the 1-based update count (bias correction).  Pointers 16-byte aligned.
+ * `grad_scale` multiplies g on the fly: 1 / world_size turns the SUM all-reduce of the flat gradient buffer into
+ * DDP's mean (mmaction/apis/train.py:106-110) without a separate pass over the buffer.
  * ------------------------------------------------------------------------------------------ */
 int aim_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, void* stream);
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Classification tail -- the callers right after the backbone:
+ *   head_fwd : I3DHead.forward (mmaction/models/heads/i3d_head.py:53-73): adaptive average pool over the T frames of
+ *              feat [B, T, D] f32 (the backbone's [B, D, T, 1, 1] output stored frame-major), optional dropout as a
+ *              caller-drawn factor table drop[B, D] (0 or 1/(1-p); NULL = eval), fc_cls:
+ *              pooled[b][d] = drop[b][d] * mean_t feat[b][t][d]  (saved for backward) ; score = pooled W^T + bias.
+ *   head_bwd : dW[C, D] += dscore^T pooled ; db[C] += colsum(dscore) ; dfeat[b][t][d] = drop[b][d]/T * (dscore W)[b][d].
+ *   ce_topk  : CrossEntropyLoss hard-label path (mmaction/models/losses/cross_entropy_loss.py:78) + top-k accuracy
+ *              (mmaction/core/evaluation/accuracy.py:90-109, numpy argsort tie order: a label is in the top k iff
+ *              fewer than k classes score higher or tie with a larger index), all on the device:
+ *              out3 = {mean_b(-log softmax(score)[label]), top1, top5} ; dscore[B, C] = (softmax - onehot) / B.
+ *              One workgroup per sample writes per-sample terms, the last pass sums them in sample order (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int aim_head_fwd(const float* feat, const float* drop, const float* W, const float* bias, float* pooled, float* score,
+                 int B, int T, int D, int C, void* stream);
+int aim_head_bwd(const float* dscore, const float* pooled, const float* drop, const float* W, float* dW, float* db,
+                 float* dfeat, int B, int T, int D, int C, void* stream);
+int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* per_sample /* [B, 3] scratch */,
+                float* out3, int B, int C, int k2 /* second k of the accuracy pair, 5 */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,10 +54,18 @@ def _worker(rank, world, port, q):
     opt.zero_grad()
     losses = model(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)
     losses["loss_cls"].backward()
+    assert len(opt._buckets) == 2                    # layers 1 and 0 are early buckets of the flat buffer
     opt.all_reduce_grads()
-    grad = opt.flat_g.detach().cpu().clone()
+    assert opt.early_launches == 2 and not opt._works and not opt._reduced      # both started from inside backward
+    # the collective is a SUM; the mean's 1 / world is folded into aim_adamw_flat(grad_scale=)
+    grad = (opt.flat_g.detach() / world).cpu().clone()
     opt.step()
     after = opt.flat_p.detach().cpu().clone()
+    # gradient accumulation: a micro-step under no_sync() starts no collective
+    with opt.no_sync():
+        model(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)["loss_cls"].backward()
+        opt.all_reduce_grads()
+    assert opt.early_launches == 2
     q.put((rank, grad.numpy(), after.numpy()))      # by value: the worker exits before the parent reads
     dist.barrier()
     dist.destroy_process_group()
@@ -90,6 +98,46 @@ def test_two_ranks_match_single_process():
     assert rel < 2e-2, rel          # bf16 kernels, different batch tiling: not bitwise
     opt.step()
     assert all(torch.equal(p.detach(), frozen_before[n]) for n, p in model.named_parameters() if n in frozen_before)
+    # the two-rank parameters after one step == the single-process ones (same mean gradient, same AdamW)
+    relp = ((a0 - opt.flat_p.detach().cpu()).norm() / a0.norm()).item()
+    assert relp < 1e-3, relp
+
+
+def test_flat_adamw_state_dict_is_torch_compatible():
+    """FlatAdamW.state_dict() loads into torch.optim.AdamW over the same parameter order (and back): checkpoints
+    written by mmcv's hook (mmcv_custom/runner/checkpoint.py:39-80 stores optimizer.state_dict() as is) interchange."""
+    from aim_amd.dist import build_optimizer
+    cfg = dict(type='AdamW', lr=1e-2, weight_decay=0.05, paramwise_cfg=dict(custom_keys={'ln_post': dict(decay_mult=0.)}))
+    imgs, label = _data()
+    model = _build()
+    opt = build_optimizer(model, cfg)
+    for _ in range(2):
+        opt.zero_grad()
+        model(imgs.cuda(), label.cuda(), return_loss=True)["loss_cls"].backward()
+        opt.step()
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and all({"step", "exp_avg", "exp_avg_sq"} == set(v) for v in sd["state"].values())
+    # torch's AdamW over the same parameters in the same group order accepts it and continues identically
+    groups = [dict(params=list(g["params"]), lr=g["lr"], weight_decay=g["weight_decay"]) for g in opt.param_groups]
+    topt = torch.optim.AdamW(groups, lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    topt.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    fake = torch.randn(opt.flat_g.shape, generator=g).cuda() * 1e-3
+    before = opt.flat_p.detach().clone()
+    opt.flat_g.copy_(fake)
+    opt.step()
+    after_flat = opt.flat_p.detach().clone()
+    opt.flat_p.copy_(before)                # params are views of flat_p: rewind, then let torch step from the same state
+    opt.flat_g.copy_(fake)
+    topt.step()
+    assert ((opt.flat_p - after_flat).abs().max() / after_flat.abs().max()).item() < 1e-5
+    # and back
+    model2 = _build()
+    opt2 = build_optimizer(model2, cfg)
+    opt2.load_state_dict(topt.state_dict())
+    assert opt2.step_count == 3
+    a, b = opt2.state_dict()["state"], topt.state_dict()["state"]
+    assert all(torch.equal(a[k]["exp_avg"], b[k]["exp_avg"]) and torch.equal(a[k]["exp_avg_sq"], b[k]["exp_avg_sq"]) for k in b)
 
 
 def test_gradient_accumulation_matches_full_batch():

@@ -402,3 +402,76 @@ def test_errors_are_loud():
         ops.gemm(a, w, ops.EPI_BF16, torch.zeros((8, 8), dtype=torch.bfloat16, device=DEV))
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.gemm(a.cpu(), w, ops.EPI_BF16, torch.zeros((8, 8), dtype=torch.bfloat16, device=DEV))
+
+
+# ---- classification tail: I3DHead + CrossEntropyLoss + top-k on HIP kernels ------------------------
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("B,T,D,C,drop", [(64, 8, 768, 400, True), (3, 4, 128, 7, False), (1, 2, 64, 5, True)])
+def test_head_and_ce_topk_kernels(B, T, D, C, drop):
+    """aim_head_fwd/bwd + aim_ce_topk against the plain PyTorch fp32 ops of the reference's tail
+    (i3d_head.py:53-73, cross_entropy_loss.py:78, accuracy.py:90-109)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from aim_amd import ops
+    from aim_amd.recognizer import top_k_accuracy
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    feat = torch.randn((B, T, D), generator=g).to(DEV)
+    W = (torch.randn((C, D), generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = (torch.randn((C,), generator=g) * 0.1).to(DEV).requires_grad_(True)
+    label = torch.randint(0, C, (B,), generator=g).to(DEV)
+    mask = (torch.empty((B, D)).bernoulli_(0.5, generator=g) / 0.5).to(DEV) if drop else None
+    # reference ops
+    fr = feat.clone().requires_grad_(True)
+    pooled_ref = fr.mean(1) * (mask if drop else 1.0)
+    score_ref = F.linear(pooled_ref, W, b)
+    loss_ref = F.cross_entropy(score_ref, label)
+    gf, gW, gb = torch.autograd.grad(loss_ref, [fr, W, b])
+    # kernels
+    pooled, score = ops.head_fwd(feat, mask, W.detach(), b.detach())
+    out3, dscore = ops.ce_topk(score, label)
+    dW, db, dfeat = ops.head_bwd(dscore, pooled, mask, W.detach(), T)
+    torch.cuda.synchronize()
+    assert _rel(score, score_ref) < 1e-5 and _rel(pooled, pooled_ref) < 1e-6
+    assert abs(float(out3[0]) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+    t1, t5 = top_k_accuracy(score_ref.detach().cpu().numpy(), label.cpu().numpy(), (1, 5))
+    assert abs(float(out3[1]) - t1) < 1e-6 and abs(float(out3[2]) - t5) < 1e-6
+    assert _rel(dW, gW) < 1e-5 and _rel(db, gb) < 1e-5 and _rel(dfeat, gf) < 1e-5
+
+
+def test_head_modules_use_the_kernels_and_match_autograd():
+    """I3DHead.forward / .loss on GPU tensors: same numbers as the eager path on a CPU copy, gradients included, and
+    exact top-k tie handling (numpy argsort order) with tied scores."""
+    import aim_amd
+    torch.manual_seed(0)
+    head = aim_amd.I3DHead(num_classes=11, in_channels=96, dropout_ratio=0.0)
+    head.init_weights()
+    ref = aim_amd.I3DHead(num_classes=11, in_channels=96, dropout_ratio=0.0)
+    ref.load_state_dict(head.state_dict())
+    head = head.to(DEV).train()
+    x = torch.randn(6, 96, 4, 1, 1)
+    lab = torch.tensor([0, 3, 3, 10, 7, 1])
+    xs = x.to(DEV).requires_grad_(True)
+    sc = head(xs)
+    losses = head.loss(sc, lab.to(DEV))
+    losses["loss_cls"].backward()
+    xr = x.clone().requires_grad_(True)
+    scr = ref(xr)
+    lr = ref.loss(scr, lab)
+    lr["loss_cls"].backward()
+    assert set(losses) == {"top1_acc", "top5_acc", "loss_cls"}
+    assert _rel(sc, scr) < 1e-5 and abs(float(losses["loss_cls"]) - float(lr["loss_cls"])) < 1e-5
+    assert float(losses["top1_acc"]) == float(lr["top1_acc"]) and float(losses["top5_acc"]) == float(lr["top5_acc"])
+    assert _rel(xs.grad, xr.grad) < 1e-5
+    assert _rel(head.fc_cls.weight.grad, ref.fc_cls.weight.grad) < 1e-5 and _rel(head.fc_cls.bias.grad, ref.fc_cls.bias.grad) < 1e-5
+    # ties: all-equal scores -> the label is in the top k iff fewer than k LARGER indices exist (numpy argsort order)
+    from aim_amd import ops
+    from aim_amd.recognizer import top_k_accuracy
+    s = torch.zeros((4, 9), device=DEV)
+    labs = torch.tensor([8, 4, 3, 0], device=DEV)
+    out3, _ = ops.ce_topk(s, labs, need_grad=False)
+    t1, t5 = top_k_accuracy(s.cpu().numpy(), labs.cpu().numpy(), (1, 5))
+    assert float(out3[1]) == t1 and float(out3[2]) == t5
