@@ -242,8 +242,11 @@ class FlatAdamW:
                                       exp_avg_sq=self.flat_v[off:off + n].view_as(p).clone())
                 ids.append(idx)
                 idx += 1
+            # the full key set of torch.optim.AdamW's groups: a loader that takes the saved group as is (torch does) must
+            # find decoupled_weight_decay=True, or it would run Adam with L2 regularisation instead
             groups.append(dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
-                               amsgrad=False, params=ids))
+                               amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                               fused=None, decoupled_weight_decay=True, params=ids))
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):

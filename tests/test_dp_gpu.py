@@ -130,7 +130,9 @@ def test_flat_adamw_state_dict_is_torch_compatible():
     opt.flat_p.copy_(before)                # params are views of flat_p: rewind, then let torch step from the same state
     opt.flat_g.copy_(fake)
     topt.step()
-    assert ((opt.flat_p - after_flat).abs().max() / after_flat.abs().max()).item() < 1e-5
+    for p, off, n in opt._views:          # (the padding slots between tensors belong to nobody)
+        d = (opt.flat_p[off:off + n] - after_flat[off:off + n]).abs().max().item()
+        assert d < 1e-6, (off, n, d)
     # and back
     model2 = _build()
     opt2 = build_optimizer(model2, cfg)
