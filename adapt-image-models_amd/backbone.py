@@ -155,6 +155,20 @@ class _Frozen:
         self.b2row = b2.detach().float().reshape(1, -1).contiguous()
 
 
+class _Frozen8:
+    """fp8 e4m3 operands of one block for the inference path (BASELINE configs[4]): every large GEMM weight is
+    quantised once per output channel (``ops.quantize_fp8_rows``); the MLP and its adapter keep their concatenated
+    form ([W_fc ; D_fc1] along N, [W_proj | D_fc2] along K).  Built when a weight changes, not per step."""
+
+    def __init__(self, blk: ResidualAttentionBlock):
+        a, ma = blk.attn, blk.MLP_Adapter
+        q = ops.quantize_fp8_rows
+        self.Wqkv, self.sqkv = q(a.in_proj_weight)
+        self.Wo, self.so = q(a.out_proj.weight)
+        self.Wcat1, self.s1 = q(torch.cat([blk.mlp.c_fc.weight.detach().float(), ma.D_fc1.weight.detach().float()], 0))
+        self.Wcat2, self.s2 = q(torch.cat([blk.mlp.c_proj.weight.detach().float(), ma.D_fc2.weight.detach().float()], 1))
+
+
 class _AdapterW:
     """bf16 operands of one adapter for this step (weights are trainable: re-cast when they change).
     ``bufs`` = already staged persistent operand buffers (the model's cast table filled them)."""
@@ -401,8 +415,13 @@ def _adapter_fwd_small(x_bf, ad: _AdapterW, rows, r, D, ar: _Arena, out_f32: boo
     return out, pre, h
 
 
-def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, dms2, save: bool):
-    """x: [B*T*N, D] f32 -> x2 (same shape).  Returns (x2, ctx) with ctx the tensors backward needs."""
+def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, dms2, save: bool, f8: Optional[_Frozen8] = None):
+    """x: [B*T*N, D] f32 -> x2 (same shape).  Returns (x2, ctx) with ctx the tensors backward needs.
+
+    ``f8`` (inference only, ``save`` must be False): the four large GEMMs of the block run on fp8 e4m3 operands
+    (``aim_gemm_fp8``); their A operands are written as fp8 by the producing kernel (LayerNorm, attention, the FC
+    epilogue).  The class-token chain (B*T rows) and the lamda statistics stay on the bf16 kernels."""
+    assert f8 is None or not save
     dev = x.device
     M, D = x.shape
     BT = B * T
@@ -437,13 +456,18 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
             ops.gemm(xl_cls, fz.Wqkv, ops.EPI_BF16, qkv_cls, bias=fz.bqkv)
             probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv_cls, 1)      # "N = 1": the rows ARE the class tokens
     # main stream: ln_1 (once) + fused QKV projection
-    xl = _empty((M, D), BF16, dev)
-    mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
-    ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
     qkv = _empty((M, 3 * D), BF16, dev)
-    # this launch leaves CUs to the class-token chain running beside it (a per-call argument, not library state)
-    ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv,
-             reserve_cus=_QKV_RESERVE if (_CLS_EARLY and fork.enabled) else 0)
+    reserve = _QKV_RESERVE if (_CLS_EARLY and fork.enabled) else 0     # CUs left to the class-token chain (per-call argument)
+    if f8 is not None:
+        xl = _empty((M, D), ops.FP8, dev)
+        mean1 = rstd1 = None
+        ops.layernorm_fwd_fp8(x, fz.g1, fz.b1, M, D, D, xl)
+        ops.gemm_fp8(xl, f8.Wqkv, f8.sqkv, ops.EPI_BF16, qkv, bias=fz.bqkv, reserve_cus=reserve)
+    else:
+        xl = _empty((M, D), BF16, dev)
+        mean1, rstd1 = _empty((M,), F32, dev), _empty((M,), F32, dev)
+        ops.layernorm_fwd(x, fz.g1, fz.b1, M, D, D, y_bf16=xl, mean=mean1, rstd=rstd1)
+        ops.gemm(xl, fz.Wqkv, ops.EPI_BF16, qkv, bias=fz.bqkv, reserve_cus=reserve)
     del xl
     if not _CLS_EARLY:
         with fork.side():
@@ -493,9 +517,13 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
             fork.sync_side_to_main()
         with fork.side():
             lam, oml, sin, sv, s_pre, s_h = lamda_chain()
-    ao = _empty((M, D), BF16, dev)
-    lse = _empty((BT, H, N), F32, dev)
-    ops.attn_fwd(qkv, ao, lse, BT, N, H)
+    if f8 is not None:
+        ao, lse = _empty((M, D), ops.FP8, dev), None
+        ops.attn_fwd_fp8(qkv, ao, BT, N, H)
+    else:
+        ao = _empty((M, D), BF16, dev)
+        lse = _empty((BT, H, N), F32, dev)
+        ops.attn_fwd(qkv, ao, lse, BT, N, H)
     fork.join()
     if not _LAMBDA_ON_SIDE:
         if part_ready is not None:
@@ -503,6 +531,17 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         lam, oml, sin, sv, s_pre, s_h = lamda_chain()
     # x1 = x + (1 - lamda) * out_proj(ao) + drop_path(scale * s_vec)
     x1 = _empty((M, D), F32, dev)
+    H4 = 4 * D
+    if f8 is not None:
+        ops.gemm_fp8(ao, f8.Wo, f8.so, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
+        xn = _empty((M, D), ops.FP8, dev)
+        ops.layernorm_fwd_fp8(x1, fz.g2, fz.b2, M, D, D, xn)
+        hcat = _empty((M, H4 + r), ops.FP8, dev)
+        ops.gemm_fp8(xn, f8.Wcat1, f8.s1, ops.EPI_ACT8, hcat, bias=fz.bcat1, act=ops.ACT_QGELU, n_split=H4,
+                     act2=ops.ACT_GELU, at=dms2, ntok=N)
+        x2 = _empty((M, D), F32, dev)
+        ops.gemm_fp8(hcat, f8.Wcat2, f8.s2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
+        return x2, None
     ops.gemm(ao, fz.Wo, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
     # joint adaptation (:285-286)
     xn = _empty((M, D), BF16, dev)
@@ -510,7 +549,6 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
     # one GEMM for [c_fc | D_fc1] (N = 4D + r; QuickGELU on the MLP columns, dms2 * GELU on the adapter's)
     # and one for [c_proj | D_fc2] (K = 4D + r); the adapter's token-scaled bias rides along as `vec`.
-    H4 = 4 * D
     hcat_pre, hcat = _empty((M, H4 + r), BF16, dev), _empty((M, H4 + r), BF16, dev)
     ops.gemm(xn, fz.Wcat1, ops.EPI_ACT, hcat, bias=fz.bcat1, out2=hcat_pre, act=ops.ACT_QGELU, n_split=H4,
              act2=ops.ACT_GELU, at=dms2, ntok=N)
@@ -680,11 +718,13 @@ class _BackboneFn(torch.autograd.Function):
         # blocks
         ctxs: List[Optional[dict]] = []
         training = model.training
+        f8 = model._fp8_operands() if (model.inference_precision == 'fp8' and not need_grad and M >= 1024) else None
         for i in range(L):
             blk = model.transformer.resblocks[i]
             dms1 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
             dms2 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
-            x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad)
+            x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad,
+                                  f8=None if f8 is None else f8[i])
             ctxs.append(c)
         # ln_post on the class rows only (LayerNorm is per-row; vit_clip.py:452-453)
         gw, gb = lnp_w.detach().float().contiguous(), lnp_b.detach().float().contiguous()
@@ -796,6 +836,10 @@ class ViT_CLIP(nn.Module):
         self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
         self.grad_ready_hook = None                 # fn(layer, in_place, streams): set by dist.FlatAdamW (overlapped all-reduce)
+        self._fp8_cache = None
+        # inference precision of the large GEMMs: 'bf16' (default, the training kernels) or 'fp8' (BASELINE configs[4]:
+        # fp8 e4m3 operands on the block-scaled MFMA; no-grad forwards only).  AIM_INFER_FP8=1 selects fp8 globally.
+        self.inference_precision = 'fp8' if os.environ.get("AIM_INFER_FP8", "0") == "1" else 'bf16'
         self._cast_table = None
 
     # ---- reference API ------------------------------------------------------------------------
@@ -879,6 +923,20 @@ class ViT_CLIP(nn.Module):
                    blocks=[_Frozen(b) for b in self.transformer.resblocks])
         self._frozen_cache = (key, out)
         return out
+
+    def set_inference_precision(self, precision: str):
+        """'bf16' | 'fp8': operand type of the large GEMMs in no-grad forwards (training always runs bf16)."""
+        if precision not in ('bf16', 'fp8'):
+            raise ValueError("inference precision must be 'bf16' or 'fp8'")
+        self.inference_precision = precision
+        return self
+
+    def _fp8_operands(self):
+        """Per-block fp8 operands; rebuilt only when any block weight changed or moved."""
+        key = tuple((p.data_ptr(), p._version) for p in self.transformer.parameters())
+        if self._fp8_cache is None or self._fp8_cache[0] != key:
+            self._fp8_cache = (key, [_Frozen8(b) for b in self.transformer.resblocks])
+        return self._fp8_cache[1]
 
     def _stage_adapters(self, frozen, params):
         """Re-cast every adapter weight (fp32 master) into its persistent bf16 operand buffers with one

@@ -51,6 +51,19 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
     return r;
 }
 
+// four floats -> four OCP fp8 e4m3 bytes (saturating: |x| is clamped to the largest finite e4m3, 448; the inference
+// path's activations are cast this way by their producing kernel)
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+    b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f);
+    d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // QuickGELU x*sigmoid(1.702x) (reference vit_clip.py:80-82) and its derivative
 // sigmoid through v_exp_f32 (base 2) + v_rcp_f32: no IEEE division sequence in the GEMM epilogues
 __device__ __forceinline__ float sigmoid_1702(float x) {

@@ -5,11 +5,12 @@
 #include <hip/hip_runtime.h>
 
 typedef aim_gemm_args GemmArgs;
-enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, EPI_F32 = AIM_EPI_F32, EPI_EXPSUM = AIM_EPI_EXPSUM };
+enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, EPI_F32 = AIM_EPI_F32, EPI_EXPSUM = AIM_EPI_EXPSUM, EPI_ACT8 = AIM_EPI_ACT8 };
 enum { ACT_QGELU = AIM_ACT_QGELU, ACT_GELU = AIM_ACT_GELU };
 
 int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st);
 int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st);
+int aim_gemm256_fp8_launch(const GemmArgs& g, int epi, hipStream_t st);
 // EXPSUM problems of one 256x256 tile per batch item run on the persistent kernel (8 partial slots per item)
 static inline bool aim_expsum_use256(int M, int N) {
     static const bool on = [] { const char* e = getenv("AIM_EXPSUM_256"); return !e || atoi(e) != 0; }();

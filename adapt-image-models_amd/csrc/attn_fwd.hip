@@ -27,7 +27,8 @@ namespace {
 // NKT: number of 16-key tiles of the LDS images (even).  NFULL: key tiles below NFULL are known to lie entirely below N,
 // so only tiles >= NFULL carry masking code (N = 197: NKT = 14, NFULL = 12; masking every tile costs ~1.5x the
 // softmax's useful vector instructions in compares, selects and spilled condition masks).
-template <int NKT, int NFULL>
+// OUT8: the output is written as fp8 e4m3 bytes (inference: operand of the fp8 out_proj GEMM) instead of bf16
+template <int NKT, int NFULL, bool OUT8 = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int N, int H
 #ifdef AIM_X_STAMPS
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
             }
         sum = quad_sum(sum);
         const float inv = 1.0f / sum;
-        if (fq == 0 && q < N) lse[((long long)bt * H + h) * N + q] = mx * 0.125f + __logf(sum);
+        if (fq == 0 && q < N && lse) lse[((long long)bt * H + h) * N + q] = mx * 0.125f + __logf(sum);
 
         ATT_STAMPQ(2);
         f32x4 o[4];
@@ -165,7 +166,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
             }
         }
         ATT_STAMPQ(3);
-        {
+        if constexpr (OUT8) {
+            // fp8 bytes: the lane owns 4 consecutive head-dim elements of tile dt -> one 4-byte store each
+            unsigned char* op8 = (unsigned char*)out + ((long long)bt * N + (q < N ? q : 0)) * D + h * 64 + fq * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                if (q < N) *(unsigned*)(op8 + dt * 16) = pack4_fp8(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        } else {
             // 16-byte stores: tiles (dt, dt+1) are paired across the even / odd 16-lane rows (aim_common.h pair_rows16), so a
             // lane writes 8 consecutive head-dim elements and a row's four lanes cover 64 contiguous bytes
             bf16_t* op = out + ((long long)bt * N + (q < N ? q : 0)) * D + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
@@ -187,9 +194,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
 #endif
 }
 
-template <int NKT, int NFULL>
+template <int NKT, int NFULL, bool OUT8 = false>
 int launch_nf(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
-    hipLaunchKernelGGL((attn_fwd_kernel<NKT, NFULL>), dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_fwd_kernel<NKT, NFULL, OUT8>), dim3(BT * H), dim3(512), NKT * 16 * 128 * 2, st, (const bf16_t*)qkv,
                        (bf16_t*)out, lse, N, H
 #ifdef AIM_X_STAMPS
                        , g_attn_probe
@@ -200,10 +207,10 @@ int launch_nf(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int
 }
 
 // masking code only on the last two key tiles when N reaches into them, on every tile otherwise
-template <int NKT>
+template <int NKT, bool OUT8 = false>
 int launch(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, hipStream_t st) {
-    if ((N >> 4) >= NKT - 2) return launch_nf<NKT, NKT - 2>(qkv, out, lse, BT, N, H, st);
-    return launch_nf<NKT, 0>(qkv, out, lse, BT, N, H, st);
+    if ((N >> 4) >= NKT - 2) return launch_nf<NKT, NKT - 2, OUT8>(qkv, out, lse, BT, N, H, st);
+    return launch_nf<NKT, 0, OUT8>(qkv, out, lse, BT, N, H, st);
 }
 
 }  // namespace
@@ -216,4 +223,15 @@ extern "C" int aim_attn_fwd(const aim_bf16* qkv, aim_bf16* out, float* lse, int 
     if (N <= 64) return launch<4>(qkv, out, lse, BT, N, H, st);
     if (N <= 224) return launch<14>(qkv, out, lse, BT, N, H, st);
     return launch<18>(qkv, out, lse, BT, N, H, st);
+}
+
+extern "C" int aim_attn_fwd_fp8(const aim_bf16* qkv, uint8_t* out_fp8, float* lse, int BT, int N, int H, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 0 && H > 0 && N <= 288, "attn_fwd_fp8: unsupported shape BT=%d N=%d H=%d (N <= 288)", BT, N, H);
+    AIM_CHECK_ARG(qkv && out_fp8, "attn_fwd_fp8: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    aim_bf16* out = (aim_bf16*)out_fp8;
+    if (N <= 32) return launch<2, true>(qkv, out, lse, BT, N, H, st);
+    if (N <= 64) return launch<4, true>(qkv, out, lse, BT, N, H, st);
+    if (N <= 224) return launch<14, true>(qkv, out, lse, BT, N, H, st);
+    return launch<18, true>(qkv, out, lse, BT, N, H, st);
 }

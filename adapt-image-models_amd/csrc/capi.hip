@@ -22,6 +22,19 @@ extern "C" int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch,
     return aim_gemm_launch(*args, epilogue, batch, (hipStream_t)stream);
 }
 
+extern "C" int aim_gemm_fp8(const aim_gemm_args* args, int epilogue, void* stream) {
+    AIM_CHECK_ARG(args != nullptr, "gemm_fp8: null args");
+    const GemmArgs& g = *args;
+    AIM_CHECK_ARG(g.M >= 1024 && g.N >= 64 && g.K > 0, "gemm_fp8: large-M problems only (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    AIM_CHECK_ARG((g.K % 16) == 0 && (g.lda % 16) == 0 && (g.ldw % 16) == 0, "gemm_fp8: K/lda/ldw must be multiples of 16 (K=%d lda=%d ldw=%d)", g.K, g.lda, g.ldw);
+    AIM_CHECK_ARG((g.N % 8) == 0 && (g.n_split % 8) == 0 && (g.ldo % 8) == 0, "gemm_fp8: N, n_split and ldo must be multiples of 8");
+    AIM_CHECK_ARG((((g.K + 127) / 128) & 1) == 0, "gemm_fp8: ceil(K / 128) must be even (K=%d)", g.K);
+    AIM_CHECK_ARG(g.A && g.W && g.out && !g.xrow, "gemm_fp8: null operand / unsupported xrow");
+    if (epilogue == EPI_F32) AIM_CHECK_ARG((g.ldr % 4) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128), "gemm_fp8: F32 epilogue strides");
+    if (g.af || g.at || g.vec) AIM_CHECK_ARG(g.ntok > 0, "gemm_fp8: ntok required with row factors");
+    return aim_gemm256_fp8_launch(g, epilogue, (hipStream_t)stream);
+}
+
 extern "C" int aim_gemm_expsum_tiles(int M, int N) {
     return aim_expsum_use256(M, N) ? 8 : ((M + 127) / 128) * ((N + 127) / 128);
 }

@@ -52,6 +52,8 @@ struct TileSrc {
 };
 
 // A batched problem (strideA / strideW between items) is walked as extra row tiles: virtual row tile tmv = z * tiles_m1 + tm.
+// ES = operand element size in bytes (2: bf16, 1: fp8 e4m3); strides and K are in elements
+template <int ES>
 __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int ntiles, int tiles_n, int tiles_m1, int wave,
                                              int srow, int schunk) {
     TileSrc t;
@@ -62,18 +64,18 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
     t.m0 = tm * 256;
     t.n0 = tn * 256;
     const int rowsA = live ? g.M - t.m0 : 0, rowsW = live ? g.N - t.n0 : 0;
-    const bf16_t* Ab = (const bf16_t*)g.A + (long long)z * g.strideA + (long long)t.m0 * g.lda;
-    const bf16_t* Wb = (const bf16_t*)g.W + (long long)z * g.strideW + (long long)t.n0 * g.ldw;
-    t.rA = make_rsrc(Ab, live ? ((long long)(rowsA - 1) * g.lda + g.K) * 2 : 0);
-    t.rW = make_rsrc(Wb, live ? ((long long)(rowsW - 1) * g.ldw + g.K) * 2 : 0);
+    const char* Ab = (const char*)g.A + ((long long)z * g.strideA + (long long)t.m0 * g.lda) * ES;
+    const char* Wb = (const char*)g.W + ((long long)z * g.strideW + (long long)t.n0 * g.ldw) * ES;
+    t.rA = make_rsrc(Ab, live ? ((long long)(rowsA - 1) * g.lda + g.K) * ES : 0);
+    t.rW = make_rsrc(Wb, live ? ((long long)(rowsW - 1) * g.ldw + g.K) * ES : 0);
     t.rX = make_rsrc(g.xrow ? (const bf16_t*)g.xrow + (long long)z * g.ldx : nullptr, (live && g.xrow) ? (long long)g.K * 2 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = h * 128 + (wave * 2 + j) * 8 + srow;
-            t.voA[h][j] = r < rowsA ? (unsigned)((r * g.lda + schunk * 8) * 2) : AIM_OOB;
-            t.voW[h][j] = r < rowsW ? (unsigned)((r * g.ldw + schunk * 8) * 2) : AIM_OOB;
+            t.voA[h][j] = r < rowsA ? (unsigned)(r * g.lda * ES + schunk * 16) : AIM_OOB;
+            t.voW[h][j] = r < rowsW ? (unsigned)(r * g.ldw * ES + schunk * 16) : AIM_OOB;
         }
     return t;
 }
@@ -82,9 +84,15 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
 // The staging pipeline never drains at a tile boundary: a tile occupies nkp = 2*ceil(nk/2) K-slots and
 // the schedule's look-ahead (up to 3 K-tiles) simply runs into the NEXT tile's first K-tiles, so its
 // prologue latency is hidden behind this tile's last MFMAs and its epilogue.
-template <int EPI>
+// F8: operands are fp8 e4m3 bytes; a K-tile is still one 128-byte LDS row per operand row (128 elements instead of 64),
+// staged and read exactly like the bf16 image, and multiplied by ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 tile
+// (unit block scales): the lane's two 16-byte chunks (ks = 0, 1) are its 32 k-values of that instruction -- any
+// assignment of k to lanes works as long as both operands use the same one (tools/probe_mfma_fp8.hip).
+template <int EPI, bool F8>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int nbatch, int ngroups, int phase_skew,
                                                       unsigned long long* probe, int probe_cap) {
+    constexpr int ES = F8 ? 1 : 2;                // operand element bytes
+    constexpr int KT = 128 / ES;                  // elements per K-tile (one 128-byte LDS row)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
     AIM_LDS char* escr = smem + 2 * BUF;          // epilogue scratch lives beside the K-loop images
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 15, fq = lane >> 4;
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const int nk = (g.K + 63) >> 6;
+    const int nk = (g.K + KT - 1) / KT;
     // EXPSUM with an extra key: the wave whose W pieces hold tile row g.N issues one more LDS-DMA per W stage pair,
     // so its counted waits leave 5, not 4, operations in flight
     const bool xw = EPI == EPI_EXPSUM && g.xrow != nullptr && wave == ((g.N & 127) >> 4);
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int nseq = ncols > 0 ? tiles_m * ncols : 0;
     auto seq_tile = [&](int seq) { return seq < nseq ? (seq / ncols) * tiles_n + c0 + seq % ncols : ntiles; };
     int seq = rank;
-    TileSrc cur = make_tile(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
-    TileSrc nxt = make_tile(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+    TileSrc cur = make_tile<ES>(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+    TileSrc nxt = make_tile<ES>(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
 
     // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
     auto stage = [&](int buf, int which, int slot) {
@@ -134,19 +142,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 #endif
         const bool in_next = slot >= nkp;
         const int kt = in_next ? slot - nkp : slot;
-        const int k0 = kt * 64;
-        const bool kin = (k0 + schunk * 8) < g.K;
+        const int k0 = kt * KT;
+        const bool kin = (k0 + schunk * (16 / ES)) < g.K;
         AIM_LDS char* dst = smem + buf * BUF + which * HT + wave * 2048;
         const int h = which & 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (which < 2) {
                 const unsigned vo = in_next ? nxt.voA[h][j] : cur.voA[h][j];
-                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * 2) : AIM_OOB;
+                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * ES) : AIM_OOB;
                 stage_piece(in_next ? nxt.rA : cur.rA, dst + j * 1024, v);
             } else {
                 const unsigned vo = in_next ? nxt.voW[h][j] : cur.voW[h][j];
-                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * 2) : AIM_OOB;
+                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * ES) : AIM_OOB;
                 stage_piece(in_next ? nxt.rW : cur.rW, dst + j * 1024, v);
                 if constexpr (EPI == EPI_EXPSUM) {
                     // the extra key: tile-local W row g.N comes from `xrow`.  Only the 8 lanes of that row take part
@@ -160,7 +168,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     };
 
     f32x4 acc[8][4];
+    // fragments: bf16 -- two 16-byte k-substeps per row tile; fp8 -- ONE 32-byte operand of the K = 128 MFMA, held as an
+    // 8-register tuple that the two ds_read_b128 fill in place (building it from two separate 4-register values costs
+    // copies and, at this register budget, spills)
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
     bf16x8 af[4][2] = {}, bfr[4][2] = {};
+    i32x8 af8[4] = {}, bf8[4] = {};
 
     auto read_b = [&](int buf) {
 #ifdef AIM_X_NOLDS
@@ -168,9 +182,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 #endif
         const AIM_LDS char* sB = smem + buf * BUF + OFF_B + (wn >> 1) * HT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (F8) {
+                bf8[j].lo = *(const AIM_LDS i32x4*)(sB + swz_off((wn & 1) * 64 + j * 16 + frow, fq));
+                bf8[j].hi = *(const AIM_LDS i32x4*)(sB + swz_off((wn & 1) * 64 + j * 16 + frow, 4 + fq));
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = lds_read8(sB + swz_off((wn & 1) * 64 + j * 16 + frow, ks * 4 + fq));
+                for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = lds_read8(sB + swz_off((wn & 1) * 64 + j * 16 + frow, ks * 4 + fq));
+            }
+        }
     };
     auto read_a = [&](int buf, int sub) {
 #ifdef AIM_X_NOLDS
@@ -178,9 +198,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 #endif
         const AIM_LDS char* sA = smem + buf * BUF + OFF_A + wm * HT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (F8) {
+                af8[i].lo = *(const AIM_LDS i32x4*)(sA + swz_off(sub * 64 + i * 16 + frow, fq));
+                af8[i].hi = *(const AIM_LDS i32x4*)(sA + swz_off(sub * 64 + i * 16 + frow, 4 + fq));
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[i][ks] = lds_read8(sA + swz_off(sub * 64 + i * 16 + frow, ks * 4 + fq));
+                for (int ks = 0; ks < 2; ++ks) af[i][ks] = lds_read8(sA + swz_off(sub * 64 + i * 16 + frow, ks * 4 + fq));
+            }
+        }
     };
     // 16 MFMA: A sub-block `sub` (4 m-tiles) x B tiles {jb, jb+1} x 2 k-substeps
     auto mma = [&](int sub, int jb) {
@@ -195,14 +221,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         return;
 #endif
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[sub * 4 + i][jb + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jb + j][ks], af[i][ks], acc[sub * 4 + i][jb + j], 0, 0, 0);
+                    // cbsz = blgp = 0: both operands fp8 e4m3; scale bytes 0x7F = 2^0
+                    acc[sub * 4 + i][jb + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        bf8[jb + j], af8[i], acc[sub * 4 + i][jb + j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[sub * 4 + i][jb + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jb + j][ks], af[i][ks], acc[sub * 4 + i][jb + j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define AIM_BAR() __builtin_amdgcn_s_barrier()
@@ -255,7 +291,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         // Slots >= nkp run into the NEXT tile's K-tiles (cross-tile prefetch).
         for (int it = 0; it < nkp / 2; ++it) {
             const int te = 2 * it, to = te + 1;
-            const bool odd_live = to < nk;
+            // fp8: the launcher guarantees an even number of K-tiles, so no fragment read / MFMA is conditional (a
+            // conditionally refilled 8-register fragment tuple costs copies and spills)
+            const bool odd_live = F8 ? true : (to < nk);
 #ifdef AIM_X_STAMPS
             stamp_arm = (probe != nullptr) && blockIdx.x == 0 && probe_i == 1 && it == 2;
 #endif
@@ -303,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
                         (float*)g.out + ((long long)(cur.z * tiles_m1 + (cur.m0 >> 8)) * tiles_n + (cur.n0 >> 8)) *
                                             (g.xrow ? 32 : 16) + wave * 2);
         else
-            wave_epilogue<EPI>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
+            wave_epilogue<EPI, F8>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
         if (probe) {        // diagnostics (aim_gemm_args.probe): per-tile timestamps of wave 0, 100 MHz ticks
             const int slot = probe_i * (int)gridDim.x + (int)blockIdx.x;
             if (tid == 0 && slot < probe_cap) {
@@ -315,16 +353,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
             ++probe_i;
         }
         cur = nxt;
-        nxt = make_tile(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+        nxt = make_tile<ES>(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256) * nbatch;
@@ -351,13 +389,24 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
         if (force_groups == 2 || force_groups == 4 || force_groups == 8) ngroups = force_groups;
     }
     static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew,
+    hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew,
                        (unsigned long long*)g.probe, g.probe ? g.probe_cap : 0);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
 }
 
 }  // namespace
+
+int aim_gemm256_fp8_launch(const GemmArgs& g, int epi, hipStream_t st) {
+    AIM_CHECK_ARG((long long)256 * g.lda < 0x7fffffffLL && (long long)256 * g.ldw < 0x7fffffffLL, "gemm_fp8: leading dimension too large");
+    switch (epi) {
+        case EPI_BF16: return launch256<EPI_BF16, true>(g, 1, st);
+        case EPI_F32: return launch256<EPI_F32, true>(g, 1, st);
+        case EPI_ACT8: return launch256<EPI_ACT8, true>(g, 1, st);
+    }
+    aim_set_error("gemm_fp8: unsupported epilogue %d (BF16, F32, ACT8)", epi);
+    return 1;
+}
 
 int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st) {
     AIM_CHECK_ARG((long long)256 * g.lda * 2 < 0x7fffffffLL && (long long)256 * g.ldw * 2 < 0x7fffffffLL, "gemm256: leading dimension too large");

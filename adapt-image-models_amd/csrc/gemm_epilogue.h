@@ -197,7 +197,9 @@ __device__ __forceinline__ void epi_advance(unsigned& voff, unsigned step) {
     asm volatile("" : "+v"(voff));
 }
 
-template <int EPI>
+// WS: apply the per-output-channel dequantisation scale g.wscale (fp8 kernels only: compile-time, so the bf16 kernels
+// carry no extra registers)
+template <int EPI, bool WS = false>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base_in,
                                               int n_base_in, int lane) {
     const int m_base = __builtin_amdgcn_readfirstlane(m_base_in), n_base = __builtin_amdgcn_readfirstlane(n_base_in);
@@ -248,20 +250,28 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
         const bool ncol = c8 < cols_left;
         const int n = n_base + c8;
+        constexpr int OES = EPI == EPI_ACT8 ? 1 : 2;          // output element bytes (fp8 | bf16)
         const __amdgpu_buffer_rsrc_t rOut =
-            epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 2, (long long)rows_left * g.ldo * 2);
+            epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * OES, (long long)rows_left * g.ldo * OES);
         const __amdgpu_buffer_rsrc_t rOut2 = epi_rsrc(EPI == EPI_ACT ? g.out2 : nullptr,
                                                       ((long long)m_base * g.ldo2 + n_base) * 2, (long long)rows_left * g.ldo2 * 2);
         const __amdgpu_buffer_rsrc_t rAux = epi_rsrc(EPI == EPI_DACT ? g.aux : nullptr,
                                                      ((long long)m_base * g.ldaux + n_base) * 2, (long long)rows_left * g.ldaux * 2);
         const f32x4 b0 = buf_load_f4(rBias, ncol ? (unsigned)c8 * 4u : AIM_OOB);
         const f32x4 b1 = buf_load_f4(rBias, ncol ? (unsigned)c8 * 4u + 16u : AIM_OOB);
+        // per-output-channel dequantisation scale of an fp8 weight (null -> 1: the branch is on a kernel argument)
+        f32x4 ws0 = f32x4{1.f, 1.f, 1.f, 1.f}, ws1 = ws0;
+        if constexpr (WS) {
+            const __amdgpu_buffer_rsrc_t rWs = epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff);
+            ws0 = buf_load_f4(rWs, ncol ? (unsigned)c8 * 4u : AIM_OOB);
+            ws1 = buf_load_f4(rWs, ncol ? (unsigned)c8 * 4u + 16u : AIM_OOB);
+        }
         const int act = col_act(g, n);
         const bool rs_on = EPI == EPI_BF16 || g.n_split == 0 || n >= g.n_split;
-        unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * 2u : AIM_OOB;
+        unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * (unsigned)OES : AIM_OOB;
         unsigned voO2 = ncol ? (unsigned)(r8 * g.ldo2 + c8) * 2u : AIM_OOB;
         unsigned voA = ncol ? (unsigned)(r8 * g.ldaux + c8) * 2u : AIM_OOB;
-        const unsigned stO = (unsigned)g.ldo * 16u, stO2 = (unsigned)g.ldo2 * 16u, stA = (unsigned)g.ldaux * 16u;
+        const unsigned stO = (unsigned)g.ldo * 8u * (unsigned)OES, stO2 = (unsigned)g.ldo2 * 16u, stA = (unsigned)g.ldaux * 16u;
         auto load_aux = [&](bf16x8 (&ax)[4]) {
             if constexpr (EPI == EPI_DACT) {
 #pragma unroll
@@ -284,9 +294,28 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 }
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (WS) { v[e] = v0[e] * ws0[e] + b0[e]; v[4 + e] = v1[e] * ws1[e] + b1[e]; }
+                    else { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
+                }
                 bf16x8 o, pre;
-                if constexpr (EPI == EPI_BF16) {
+                if constexpr (EPI == EPI_ACT8) {
+                    // inference: activation, row factor, saturating cast to fp8 e4m3 (two per v_cvt_pk_fp8_f32)
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = rs * (act == ACT_QGELU ? quick_gelu(v[e]) : gelu_erf(v[e]));
+                        y[e] = __builtin_fminf(__builtin_fmaxf(t, -448.f), 448.f);
+                    }
+                    int w0 = 0, w1 = 0;
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w0, false);
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], w1, false);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], w1, true);
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)w0, (unsigned)w1}, rOut, voO, 0, AIM_STORE_POLICY);
+                    epi_advance(voO, stO);
+                } else if constexpr (EPI == EPI_BF16) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(rs * v[e]);
                 } else if constexpr (EPI == EPI_ACT) {
@@ -318,8 +347,10 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                             o[e] = (bf16_t)(rs * v[e] * gelu_erf_grad((float)ax[sp][e]));
                     }
                 }
-                buf_store16(rOut, voO, o);
-                epi_advance(voO, stO);
+                if constexpr (EPI != EPI_ACT8) {
+                    buf_store16(rOut, voO, o);
+                    epi_advance(voO, stO);
+                }
                 if constexpr (EPI == EPI_ACT) {
                     buf_store16(rOut2, voO2, pre);
                     epi_advance(voO2, stO2);
@@ -344,6 +375,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         const __amdgpu_buffer_rsrc_t rRes =
             epi_rsrc(g.resid, ((long long)m_base * g.ldr + n_base) * 4, (long long)rows_left * g.ldr * 4);
         const f32x4 bias4 = buf_load_f4(rBias, ncol ? (unsigned)cc * 4u : AIM_OOB);
+        f32x4 ws4 = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (WS) ws4 = buf_load_f4(epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff), ncol ? (unsigned)cc * 4u : AIM_OOB);
         // `vec` rows are per frame, and the wave tile's 128 rows touch at most two frames (ntok >= 128, checked
         // by the launcher): both candidate rows are fetched once and selected per row
         f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f}, w1 = w0;
@@ -376,6 +409,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 for (int tt = 0; tt < 2; ++tt) {
                     const int t = sp * 2 + tt;
                     f32x4 v = *(const AIM_LDS f32x4*)(scr + (tt * 4 + rr) * EPI_RS + cc * 4);
+                    if constexpr (WS) v *= ws4;
                     if constexpr (decltype(ROWF)::value) {
                         const int r0 = grp * 32 + t * 4;           // uniform part of the tile-local row r0 + rr
                         const f32x2 f = *(const AIM_LDS f32x2*)(rowfac + rr * 2 + r0 * 2);

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16_t* __restrict__ yb, float* __restrict__ yf, long long ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int rows, int D, float eps) {
+                                                     int rows, int D, float eps, unsigned char* __restrict__ y8 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int e = 0; e < 4; ++e) y[e] = (v[c][e] - mu) * rs * g[e] + b[e];
             if (yb) *(bf16x4*)(yb + (long long)row * ldy + ch * 4) = pack4(y[0], y[1], y[2], y[3]);
             if (yf) *(f32x4*)(yf + (long long)row * ldy + ch * 4) = y;
+            if (y8) *(unsigned*)(y8 + (long long)row * ldy + ch * 4) = pack4_fp8(y[0], y[1], y[2], y[3]);
         }
     }
 }
@@ -149,6 +150,22 @@ extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     else if (nc == 4) AIM_LN_FWD(4); else AIM_LN_FWD(8);
 #undef AIM_LN_FWD
     AIM_CHECK_LAUNCH("aim_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int aim_layernorm_fwd_fp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* y_fp8,
+                                     int64_t ldy, int rows, int D, float eps, void* stream) {
+    AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_fwd_fp8: bad shape rows=%d D=%d", rows, D);
+    AIM_CHECK_ARG(x && gamma && beta && y_fp8, "layernorm_fwd_fp8: null pointer");
+    AIM_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "layernorm_fwd_fp8: strides must be multiples of 4");
+#define AIM_LN_FWD8(NC)                                                                                           \
+    hipLaunchKernelGGL(ln_fwd_kernel<NC>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, \
+                       gamma, beta, (bf16_t*)nullptr, (float*)nullptr, (long long)ldy, (float*)nullptr, (float*)nullptr, rows, D, eps, y_fp8)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_LN_FWD8(1); else if (nc == 2) AIM_LN_FWD8(2); else if (nc == 3) AIM_LN_FWD8(3);
+    else if (nc == 4) AIM_LN_FWD8(4); else AIM_LN_FWD8(8);
+#undef AIM_LN_FWD8
+    AIM_CHECK_LAUNCH("aim_layernorm_fwd_fp8");
     return 0;
 }
 

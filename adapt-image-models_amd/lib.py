@@ -30,6 +30,7 @@ class GemmArgs(Structure):
         ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32), ("n_split", c_int32), ("act2", c_int32),
         ("xrow", c_void_p), ("ldx", c_int32),
         ("reserve_cus", c_int32), ("probe", c_void_p), ("probe_cap", c_int32),
+        ("wscale", c_void_p),
     ]
 
 
@@ -43,12 +44,15 @@ SIGNATURES = {
     "aim_version": [],
     "aim_last_error": [],
     "aim_gemm_bf16": [POINTER(GemmArgs), I, I, P],
+    "aim_gemm_fp8": [POINTER(GemmArgs), I, P],
     "aim_gemm_expsum_tiles": [I, I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
+    "aim_layernorm_fwd_fp8": [P, L, P, P, P, L, I, I, F, P],
     "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, I, P, P, L, P, P, I, I, P],
     "aim_attn_fwd": [P, P, P, I, I, I, P],
+    "aim_attn_fwd_fp8": [P, P, P, I, I, I, P],
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
     "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, I, P],

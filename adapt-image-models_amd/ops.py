@@ -10,7 +10,8 @@ import torch
 
 from .lib import GemmArgs, check, load_library
 
-EPI_BF16, EPI_ACT, EPI_DACT, EPI_F32, EPI_EXPSUM = 0, 1, 2, 3, 4
+EPI_BF16, EPI_ACT, EPI_DACT, EPI_F32, EPI_EXPSUM, EPI_ACT8 = 0, 1, 2, 3, 4, 5
+FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950); stored as bytes
 ACT_QGELU, ACT_GELU = 0, 1
 
 BF16 = torch.bfloat16
@@ -117,6 +118,74 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
         e1.record()
         GEMM_TIMER.records.append((epi, 2.0 * g.M * g.N * g.K * batch, e0, e1))
     return out
+
+
+def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, epi: int, out: torch.Tensor, *, bias=None,
+             resid=None, af=None, at=None, vec=None, bt=None, ntok: int = 0, act: int = 0, n_split: int = 0, act2: int = 0,
+             ldv: Optional[int] = None, reserve_cus: int = 0):
+    """``out = epilogue(wscale[n] * (a8 @ w8.T))``: fp8 e4m3 operands on the block-scaled MFMA (inference only).
+    ``a8`` [M, K], ``w8`` [N, K] are float8_e4m3fn (or uint8 views); ``out`` bf16 (EPI_BF16), f32 (EPI_F32) or fp8
+    (EPI_ACT8)."""
+    lib = load_library()
+    for n_, t_ in (("a8", a8), ("w8", w8)):
+        if not t_.is_cuda or t_.element_size() != 1 or t_.stride(-1) != 1:
+            raise TypeError(f"{n_}: expected a GPU fp8 (1-byte) tensor with a contiguous last dimension")
+    for n_, t_ in (("wscale", wscale), ("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
+        _chk(t_, F32, n_)
+    g = GemmArgs()
+    g.A, g.W = a8.data_ptr(), w8.data_ptr()
+    g.M, g.K, g.N = a8.shape[0], a8.shape[1], w8.shape[0]
+    g.lda, g.ldw = a8.stride(0), w8.stride(0)
+    g.bias, g.resid, g.wscale = _p(bias), _p(resid), wscale.data_ptr()
+    g.ldr = resid.stride(0) if resid is not None else 0
+    g.af, g.at, g.vec, g.bt = _p(af), _p(at), _p(vec), _p(bt)
+    g.ldv = (vec.stride(0) if ldv is None else ldv) if vec is not None else 0
+    g.ntok = ntok
+    g.out, g.ldo = out.data_ptr(), out.stride(0)
+    g.act, g.n_split, g.act2, g.scale = act, n_split, act2, 1.0
+    g.reserve_cus = int(reserve_cus)
+    if epi == EPI_BF16:
+        _chk(out, BF16, "out")
+    elif epi == EPI_F32:
+        _chk(out, F32, "out")
+    elif out.element_size() != 1:
+        raise TypeError("out: EPI_ACT8 writes fp8 bytes")
+    timed = GEMM_TIMER.enabled and 2.0 * g.M * g.N * g.K >= GEMM_TIMER.min_flops
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.aim_gemm_fp8(byref(g), epi, _stream()), "aim_gemm_fp8")
+    if timed:
+        e1.record()
+        GEMM_TIMER.records.append((100 + epi, 2.0 * g.M * g.N * g.K, e0, e1))
+    return out
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """Per-output-channel fp8 quantisation of a weight ``[N, K]`` (one-off host-side staging, not a hot-path op):
+    ``scale[n] = amax_n / 448``, ``w8 = e4m3(w / scale)``.  Returns (w8 as float8_e4m3fn on w's device, scale f32)."""
+    wf = w.detach().float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-12)
+    scale = amax / 448.0
+    q = (wf / scale[:, None]).clamp_(-448.0, 448.0)
+    # the cast itself runs on the CPU: every torch build rounds f32 -> e4m3fn to nearest-even there
+    w8 = q.cpu().to(FP8).to(w.device)
+    return w8.contiguous(), scale.contiguous()
+
+
+def layernorm_fwd_fp8(x, gamma, beta, rows, D, ldx, y8, ldy=None, eps: float = 1e-5):
+    _chk(x, F32, "x"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta")
+    if y8.element_size() != 1 or not y8.is_cuda:
+        raise TypeError("y8: expected a GPU fp8 (1-byte) tensor")
+    check(load_library().aim_layernorm_fwd_fp8(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y8.data_ptr(),
+                                               D if ldy is None else ldy, rows, D, eps, _stream()), "aim_layernorm_fwd_fp8")
+
+
+def attn_fwd_fp8(qkv, out8, BT, N, H, lse=None):
+    _chk(qkv, BF16, "qkv"); _chk(lse, F32, "lse")
+    if out8.element_size() != 1 or not out8.is_cuda:
+        raise TypeError("out8: expected a GPU fp8 (1-byte) tensor")
+    check(load_library().aim_attn_fwd_fp8(qkv.data_ptr(), out8.data_ptr(), _p(lse), BT, N, H, _stream()), "aim_attn_fwd_fp8")
 
 
 def expsum_tiles(M: int, N: int) -> int:

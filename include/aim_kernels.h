@@ -51,8 +51,10 @@ enum {
     AIM_EPI_DACT = 2,  /* out(bf16) = rs * (acc + bias) * act'(aux)        (aux = saved pre)    */
     AIM_EPI_F32 = 3,   /* out(f32) = resid + rs*(acc + bias) + bt[tok]*vec[frame][n]
                           (rs_bias_only != 0: out = resid + acc + rs*bias + ...)               */
-    AIM_EPI_EXPSUM = 4 /* out(f32)[batch][tile][2] = (max, sum exp(scale*acc - max)) over the
+    AIM_EPI_EXPSUM = 4,/* out(f32)[batch][tile][2] = (max, sum exp(scale*acc - max)) over the
                           valid part of each 128x128 tile (lambda statistics, :149-151)         */
+    AIM_EPI_ACT8 = 5   /* out(fp8 e4m3) = sat(rs * act(acc + bias)): inference only, nothing saved
+                          for a backward (aim_gemm_fp8)                                         */
 };
 enum { AIM_ACT_QGELU = 0, AIM_ACT_GELU = 1 };
 
@@ -95,9 +97,21 @@ typedef struct aim_gemm_args {
        per processed tile. */
     void* probe;
     int32_t probe_cap;
+    /* per-output-channel dequantisation scale of W (aim_gemm_fp8): acc is multiplied by wscale[n] before bias / act /
+       row factors.  NULL -> 1.  */
+    const float* wscale;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
+
+/* fp8 inference GEMM (BASELINE configs[4]; no reference counterpart -- the reference runs apex-O1 fp16):
+ *   C[m][n] = wscale[n] * sum_k A8[m][k] * W8[n][k]
+ * A and W hold OCP e4m3 bytes (K-contiguous; lda / ldw / K in elements, multiples of 16), products run on the
+ * block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate), fp32 accumulate.
+ * Weights are quantised once per output channel (wscale[n] = amax_n / 448), activations are saturating casts made by
+ * the producing kernel (aim_layernorm_fwd y_fp8, AIM_EPI_ACT8, aim_attn_fwd out_fp8).  Epilogues: AIM_EPI_BF16,
+ * AIM_EPI_F32, AIM_EPI_ACT8.  Large-M problems only (M >= 1024, N >= 64, N % 8 == 0). */
+int aim_gemm_fp8(const aim_gemm_args* args, int epilogue, void* stream);
 /* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
 int aim_gemm_expsum_tiles(int M, int N);
 
@@ -124,6 +138,9 @@ int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw);
 int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                       aim_bf16* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
                       int rows, int D, float eps, void* stream);
+/* inference form: y as fp8 e4m3 bytes (saturating cast, row stride ldy bytes); no statistics are saved */
+int aim_layernorm_fwd_fp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* y_fp8,
+                          int64_t ldy, int rows, int D, float eps, void* stream);
 int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0) */, int64_t lddy,
                       const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,
@@ -137,6 +154,8 @@ int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0
  *   bwd: dqkv [BT*N, 3*D] bf16 from dout [BT*N, D] bf16 (recomputes the probabilities from lse).
  * ------------------------------------------------------------------------------------------ */
 int aim_attn_fwd(const aim_bf16* qkv, aim_bf16* out, float* lse, int BT, int N, int H, void* stream);
+/* inference form: out as fp8 e4m3 bytes [BT*N, D] (operand of the fp8 out_proj GEMM); lse may be NULL */
+int aim_attn_fwd_fp8(const aim_bf16* qkv, uint8_t* out_fp8, float* lse, int BT, int N, int H, void* stream);
 int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_bf16* dout, const float* lse,
                  float* delta /* scratch [BT, H, N] f32 */, aim_bf16* dqkv, int BT, int N, int H,
                  void* stream);

@@ -312,6 +312,17 @@ FP32 = Rounding(None)
 BF16 = Rounding(torch.bfloat16)
 
 
+def q8(t: Tensor) -> Tensor:
+    """Saturating round-trip through OCP fp8 e4m3 (what the inference kernels store as GEMM operands)."""
+    return t.detach().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+
+
+def q8_rows(w: Tensor):
+    """Per-output-channel fp8 weight quantisation -> (dequantised-grid weight, scale) as ``ops.quantize_fp8_rows``."""
+    scale = w.detach().abs().amax(dim=1).clamp_min(1e-12) / 448.0
+    return q8(w.detach() / scale[:, None]), scale
+
+
 def _lin(a: Tensor, w: Tensor, b: Optional[Tensor], rnd: Rounding) -> Tensor:
     """bf16-operand / fp32-accumulate GEMM: operands rounded, result left fp32."""
     return F.linear(rnd(a), rnd(w), b)
@@ -324,7 +335,7 @@ def emu_adapter(x: Tensor, st: State, pre: str, rnd: Rounding) -> Tensor:
 
 
 def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
-              rnd: Rounding = FP32, drop_mask: Optional[Tensor] = None, return_aux: bool = False):
+              rnd: Rounding = FP32, drop_mask: Optional[Tensor] = None, return_aux: bool = False, f8: bool = False):
     """One block in the product's frame-major layout.
 
     ``x``: ``[BT, N, D]`` fp32 residual stream.  ``drop_mask``: ``[N]``, a pair of ``[N]``
@@ -341,13 +352,25 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     dh = D // heads
     W, bqkv = st[pre + "attn.in_proj_weight"], st[pre + "attn.in_proj_bias"]
     Wo, bo = st[pre + "attn.out_proj.weight"], st[pre + "attn.out_proj.bias"]
-    xl = rnd(F.layer_norm(x, (D,), st[pre + "ln_1.weight"], st[pre + "ln_1.bias"], 1e-5))
-    qkv = rnd(_lin(xl, W, bqkv, rnd))                               # [BT,N,3D] stored bf16
+    xl_f = F.layer_norm(x, (D,), st[pre + "ln_1.weight"], st[pre + "ln_1.bias"], 1e-5)
+    xl = rnd(xl_f)
+    if f8:
+        # inference path (BASELINE configs[4]): the four large GEMMs take fp8 e4m3 operands -- activations cast by the
+        # producing kernel straight from fp32, weights quantised per output channel -- with fp32 accumulation; the
+        # class-token chain keeps its own bf16 ln_1 + QKV projection on the B*T class rows
+        def lin8(a_f32, w, b):
+            w8, sc = q8_rows(w)
+            return F.linear(q8(a_f32), w8) * sc + (0 if b is None else b)
+        qkv = rnd(lin8(xl_f, W, bqkv))
+        qkv_c = rnd(_lin(xl[:, 0], W, bqkv, rnd))
+    else:
+        qkv = rnd(_lin(xl, W, bqkv, rnd))                           # [BT,N,3D] stored bf16
+        qkv_c = qkv[:, 0]
     q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
     # --- temporal attention over the T class tokens of each clip ------------
-    qc = q[:, 0].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
-    kc = k[:, 0].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
-    vc = v[:, 0].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
+    qc = qkv_c[:, :D].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
+    kc = qkv_c[:, D:2 * D].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
+    vc = qkv_c[:, 2 * D:].reshape(B, T, heads, dh).permute(0, 2, 1, 3)
     pt = ((qc @ kc.transpose(-1, -2)) / math.sqrt(dh)).softmax(-1)
     ot = rnd((pt @ vc).permute(0, 2, 1, 3).reshape(BT, D))
     ta = rnd(_lin(ot, Wo, bo, rnd))
@@ -370,15 +393,31 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     vh = v.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
     sc = (qh @ kh.transpose(-1, -2)) / math.sqrt(dh)
     pu = torch.exp(sc - sc.amax(dim=-1, keepdim=True))           # un-normalised, max 1 (what the kernel rounds)
-    ao = rnd(((rnd(pu) @ vh) / pu.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(BT, N, D))
-    proj = _lin(ao, Wo, bo, rnd)                                    # fp32 accumulators
+    ao_f = ((rnd(pu) @ vh) / pu.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(BT, N, D)
+    if f8:
+        proj = lin8(ao_f, Wo, bo)
+    else:
+        ao = rnd(ao_f)
+        proj = _lin(ao, Wo, bo, rnd)                                # fp32 accumulators
     sv = emu_adapter(rnd(lam[:, None] * crs), st, pre + "S_Adapter", rnd)   # [BT, D]
     d1, d2 = drop_mask if isinstance(drop_mask, (tuple, list)) else (drop_mask, drop_mask)
     dm = 1.0 if d1 is None else d1.reshape(1, N, 1)
     dm2 = 1.0 if d2 is None else d2.reshape(1, N, 1)
     x1 = x + (1 - lam)[:, None, None] * proj + dm * scale * sv[:, None, :]
     # --- MLP + MLP_Adapter --------------------------------------------------------
-    xn = rnd(F.layer_norm(x1, (D,), st[pre + "ln_2.weight"], st[pre + "ln_2.bias"], 1e-5))
+    xn_f = F.layer_norm(x1, (D,), st[pre + "ln_2.weight"], st[pre + "ln_2.bias"], 1e-5)
+    if f8:
+        # concatenated operands: [W_fc ; D_fc1] along N, [W_proj | D_fc2] along K (one scale per output channel of each)
+        ap = pre + "MLP_Adapter."
+        h = ref_quick_gelu(lin8(xn_f, st[pre + "mlp.c_fc.weight"], st[pre + "mlp.c_fc.bias"]))
+        a = dm2 * scale * F.gelu(lin8(xn_f, st[ap + "D_fc1.weight"], st[ap + "D_fc1.bias"]))
+        wcat2 = torch.cat([st[pre + "mlp.c_proj.weight"], st[ap + "D_fc2.weight"]], dim=1)
+        out2 = lin8(torch.cat([h, a], dim=-1), wcat2, None)
+        x2 = x1 + out2 + st[pre + "mlp.c_proj.bias"] + dm2 * scale * st[ap + "D_fc2.bias"]
+        if return_aux:
+            return x2, dict(lamda=lam, xt=xt, ow_shifted=ow, cw_shifted=cw, shift=m)
+        return x2
+    xn = rnd(xn_f)
     hpre = rnd(_lin(xn, st[pre + "mlp.c_fc.weight"], st[pre + "mlp.c_fc.bias"], rnd))
     h = rnd(ref_quick_gelu(hpre))
     mlp = _lin(h, st[pre + "mlp.c_proj.weight"], st[pre + "mlp.c_proj.bias"], rnd)
@@ -405,13 +444,13 @@ def emu_embed(imgs: Tensor, st: State, rnd: Rounding = FP32) -> Tensor:
 
 
 def emu_backbone(imgs: Tensor, st: State, heads: int, scale: float = 0.5,
-                 rnd: Rounding = FP32, layers: Optional[int] = None, drop_masks=None) -> Tensor:
+                 rnd: Rounding = FP32, layers: Optional[int] = None, drop_masks=None, f8: bool = False) -> Tensor:
     """Whole backbone in the product's dataflow: ``[B,3,T,H,W] -> [B,D,T,1,1]``."""
     B, _, T = imgs.shape[:3]
     if layers is None:
         layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
     x = emu_embed(imgs, st, rnd)
     for i in range(layers):
-        x = emu_block(x, st, i, heads, T, scale, rnd, drop_mask=None if drop_masks is None else drop_masks[i])
+        x = emu_block(x, st, i, heads, T, scale, rnd, drop_mask=None if drop_masks is None else drop_masks[i], f8=f8)
     c = F.layer_norm(x[:, 0], (x.shape[-1],), st["ln_post.weight"], st["ln_post.bias"], 1e-5)
     return c.reshape(B, T, -1).permute(0, 2, 1).unsqueeze(-1).unsqueeze(-1)
