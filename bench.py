@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2516.6        # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md: ~2.5 PF)
 GF_PER_CLIP = {"fwd": 293.1, "bwd": 314.0}   # SURVEY section 8(d), ViT-B/16 T=8, algorithmic
 GF_PER_CLIP_L14_T16 = 5608.5                 # SURVEY section 8(d), ViT-L/14 T=16 fwd+bwd, algorithmic
+GF_PER_VIEW_L14_T32 = 5405.1                 # SURVEY section 8(d), ViT-L/14 T=32 forward (inference), algorithmic
+PEAK_FP8_TFLOPS = 2 * PEAK_BF16_TFLOPS       # dense fp8 MFMA (block-scaled K=128 form): 2x bf16 (MI355X_MICROARCH.md: ~5 PF)
 ARCH = {"B16": dict(patch_size=16, width=768, layers=12, heads=12),
         "L14": dict(patch_size=14, width=1024, layers=24, heads=16)}     # configs/recognition/vit/vitclip_{base,large}_k400.py
 
@@ -36,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the ViT-L/14 16-frame block (BASELINE configs[3] shape)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the fp8 multi-view inference block (BASELINE configs[4] shape)")
     return ap.parse_args()
 
 
@@ -170,6 +173,62 @@ def secondary_l14(dev, rank, world, steps=3, warmup=1, clips=32, frames=16):
             "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
 
 
+def inference_l14(dev, rank, world, samples=4, views=3, frames=32, steps=4, warmup=2):
+    """BASELINE configs[4] per-GPU shape: ViT-L/14 + AIM, 32 frames, 3 views per sample (3-crop), multi-view test path
+    ``Recognizer3D.forward_test`` -> ``average_clip('prob')``, fp8 e4m3 GEMM operands; the bf16 path is timed beside it
+    in the same process.  Replicas only: inference shards samples over ranks with no collective."""
+    import aim_amd
+    a = ARCH["L14"]
+    cfg = dict(type='Recognizer3D',
+               backbone=dict(type='ViT_CLIP', input_resolution=224, num_frames=frames, drop_path_rate=0.2, adapter_scale=0.5,
+                             pretrained=None, **a),
+               cls_head=dict(type='I3DHead', in_channels=a["width"], num_classes=400, spatial_type='avg', dropout_ratio=0.5),
+               test_cfg=dict(average_clips='prob'))
+    torch.manual_seed(0)
+    model = aim_amd.build_model(cfg)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "D_fc2" in n:
+                p.normal_(0, 0.02)
+    model = model.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(999 + rank)
+    imgs = torch.randn((samples, views, 3, frames, 224, 224), generator=g).to(dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {}
+    for prec in ("bf16", "fp8"):
+        model.backbone.set_inference_precision(prec)
+        with torch.no_grad():
+            for _ in range(warmup):
+                model._do_test(imgs)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                probs = model._do_test(imgs)
+            fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        out[prec] = dict(views_per_s=round(samples * views * world * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 2),
+                         pred=probs.argmax(1).tolist())
+    v8 = out["fp8"]["views_per_s"]
+    return {"workload": f"BASELINE configs[4] per-GPU shape: ViT-L/14 + AIM, {frames} frames 224^2, {views} views x {samples} samples "
+                        "per step, multi-view inference (forward_test, average_clips='prob'), fp8 e4m3 GEMM operands / fp32 accumulate",
+            "value": v8, "unit": "views/s", "n_gpus": world, "steps": steps, "warmup": warmup, "dtype": "fp8",
+            "ms_per_step": out["fp8"]["ms_per_step"],
+            "fp8_mfma_frac": round(v8 / world * GF_PER_VIEW_L14_T32 / 1e3 / PEAK_FP8_TFLOPS, 4),
+            "bf16_same_process": {"views_per_s": out["bf16"]["views_per_s"], "ms_per_step": out["bf16"]["ms_per_step"],
+                                  "bf16_mfma_frac": round(out["bf16"]["views_per_s"] / world * GF_PER_VIEW_L14_T32 / 1e3 / PEAK_BF16_TFLOPS, 4)},
+            "top1_agreement_fp8_vs_bf16": sum(int(a_ == b_) for a_, b_ in zip(out["fp8"]["pred"], out["bf16"]["pred"])) / samples,
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+
+
 def main():
     args = parse()
     from aim_amd.dist import broadcast_module, build_optimizer, init_distributed
@@ -282,17 +341,26 @@ def main():
         out["roofline"] = roof
     # second shape (after the primary timed region; every rank takes part)
     sec = None
+    del model, opt, imgs, label, losses
+    torch.cuda.empty_cache()
     if not args.no_secondary and args.frames == 8:
-        del model, opt, imgs, label, losses
-        torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats(dev)
         try:
             sec = secondary_l14(dev, rank, world)
         except Exception as e:          # the primary line must still be printed
             sec = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
+    inf = None
+    if not args.no_inference and args.frames == 8:
+        torch.cuda.reset_peak_memory_stats(dev)
+        try:
+            inf = inference_l14(dev, rank, world)
+        except Exception as e:
+            inf = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
     if rank == 0:
         out["secondary"] = sec
+        out["inference"] = inf
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.frames)
         print(json.dumps(out), flush=True)
     if world > 1:
