@@ -134,12 +134,16 @@ class _Frozen:
         self.g2, self.b2 = f(blk.ln_2.weight), f(blk.ln_2.bias)
 
 
-    def cast_entries(self, name, w1, w2):
-        """(src, dst, transpose) casts that stage one adapter's weights as bf16 operands, both orientations."""
+    def cast_entries(self, name, w1, w2, b1=None):
+        """(src, dst, mode) entries that stage one adapter's weights as bf16 operands, both orientations (mode False / True =
+        plain / transposed cast; 2 = fp32 copy: the MLP_Adapter's D_fc1 bias into the concatenated bias vector)."""
         H4 = self.H4
         if name == "MLP_Adapter":      # adapter slices of the concatenated MLP operands
-            return [(w1, self.Wcat1[H4:], False), (w2, self.Wcat2[:, H4:], False),
-                    (w2, self.WcatT2[H4:], True), (w1, self.WcatT1[:, H4:], True)]
+            ent = [(w1, self.Wcat1[H4:], False), (w2, self.Wcat2[:, H4:], False),
+                   (w2, self.WcatT2[H4:], True), (w1, self.WcatT1[:, H4:], True)]
+            if b1 is not None:
+                ent.append((b1.reshape(1, -1), self.bcat1[H4:].reshape(1, -1), 2))
+            return ent
         b = self.small[name]
         return [(w1, b["W1"], False), (w1, b["W1T"], True), (w2, b["W2"], False), (w2, b["W2T"], True)]
 
@@ -150,8 +154,9 @@ class _Frozen:
             ops.cast_bf16(src, dst, transpose=tr)
         self.stage_mlp_bias(b1, b2)
 
-    def stage_mlp_bias(self, b1, b2):
-        self.bcat1[self.H4:] = b1.detach().float()
+    def stage_mlp_bias(self, b1, b2, copy_b1: bool = True):
+        if copy_b1:            # (the model's cast table copies it in its one launch instead)
+            self.bcat1[self.H4:] = b1.detach().float()
         self.b2row = b2.detach().float().reshape(1, -1).contiguous()
 
 
@@ -692,14 +697,14 @@ class _BackboneFn(torch.autograd.Function):
         # grad mode decides whether the per-block contexts (~2 GB per ViT-B layer at 64 clips) are kept
         need_grad = grad_enabled and any(ctx.needs_input_grad)
         frozen = model._frozen_operands()
-        model._stage_adapters(frozen, params)      # ONE launch casts all 36 adapters' weights to bf16 operands
+        staged_bias = model._stage_adapters(frozen, params)   # ONE launch: all 36 adapters' weights -> bf16 operands (+ biases)
         adp = []
         for i in range(L):
             d = {}
             for j, a in enumerate(_ADAPTERS):
                 k = 3 + (i * 3 + j) * 4
                 if a == "MLP_Adapter":      # shares the frozen MLP's GEMMs (concatenated operands)
-                    frozen["blocks"][i].stage_mlp_bias(params[k + 1], params[k + 3])
+                    frozen["blocks"][i].stage_mlp_bias(params[k + 1], params[k + 3], copy_b1=not staged_bias)
                 else:
                     d[a] = _AdapterW(params[k], params[k + 1], params[k + 2], params[k + 3],
                                      bufs=frozen["blocks"][i].small[a])
@@ -719,10 +724,9 @@ class _BackboneFn(torch.autograd.Function):
         ctxs: List[Optional[dict]] = []
         training = model.training
         f8 = model._fp8_operands() if (model.inference_precision == 'fp8' and not need_grad and M >= 1024) else None
+        masks = model._drop_masks(N, training, dev)          # [L, 2, N]: all layers' DropPath factors in three launches
         for i in range(L):
-            blk = model.transformer.resblocks[i]
-            dms1 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
-            dms2 = model._drop_mask(N, blk.drop_prob, blk.scale, training, dev)
+            dms1, dms2 = masks[i, 0], masks[i, 1]
             x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad,
                                   f8=None if f8 is None else f8[i])
             ctxs.append(c)
@@ -946,6 +950,8 @@ class ViT_CLIP(nn.Module):
             for j, a in enumerate(_ADAPTERS):
                 k = 3 + (i * 3 + j) * 4
                 srcs += [params[k], params[k + 2]]
+                if a == "MLP_Adapter":
+                    srcs.append(params[k + 1])
         ok = all(p.dtype == F32 and p.is_contiguous() for p in srcs)
         key = tuple(p.data_ptr() for p in srcs) + (id(frozen),)
         if ok and (self._cast_table is None or self._cast_table[0] != key):
@@ -953,17 +959,19 @@ class ViT_CLIP(nn.Module):
             for i in range(self.layers):
                 for j, a in enumerate(_ADAPTERS):
                     k = 3 + (i * 3 + j) * 4
-                    entries += frozen["blocks"][i].cast_entries(a, params[k].detach(), params[k + 2].detach())
+                    entries += frozen["blocks"][i].cast_entries(a, params[k].detach(), params[k + 2].detach(),
+                                                                params[k + 1].detach() if a == "MLP_Adapter" else None)
             self._cast_table = (key, ops.CastTable(entries, srcs[0].device))
         if ok:
             self._cast_table[1].run()
-            return
+            return True
         for i in range(self.layers):           # generic path (non-fp32 / non-contiguous masters)
             for j, a in enumerate(_ADAPTERS):
                 k = 3 + (i * 3 + j) * 4
                 for src, dst, tr in frozen["blocks"][i].cast_entries(a, params[k].detach().float().contiguous(),
                                                                      params[k + 2].detach().float().contiguous()):
                     ops.cast_bf16(src, dst, transpose=tr)
+        return False
 
     def _trainable_list(self):
         ps = [self.temporal_embedding, self.ln_post.weight, self.ln_post.bias]
@@ -982,6 +990,20 @@ class ViT_CLIP(nn.Module):
             m = torch.empty(N, dtype=F32, device=dev).bernoulli_(keep)
             return m.div_(keep).mul_(scale) if keep > 0 else m.mul_(0.)
         return torch.full((N,), float(scale), dtype=F32, device=dev)
+
+    def _drop_masks(self, N, training, dev):
+        """Both DropPath factors of every block, ``[L, 2, N]`` (same distribution as ``_drop_mask`` per call; one
+        uniform draw for the whole model instead of 2 L bernoulli launches)."""
+        blocks = self.transformer.resblocks
+        rates = torch.tensor([b.drop_prob for b in blocks], dtype=F32)
+        scale = torch.tensor([float(b.scale) for b in blocks], dtype=F32)
+        L = len(blocks)
+        if not training or float(rates.max()) <= 0.:
+            return scale.to(dev).view(L, 1, 1).expand(L, 2, N).contiguous()
+        keep = (1.0 - rates)
+        fac = torch.where(keep > 0, scale / keep.clamp_min(1e-12), torch.zeros_like(keep)).to(dev).view(L, 1, 1)
+        u = torch.rand((L, 2, N), dtype=F32, device=dev)
+        return (u < keep.to(dev).view(L, 1, 1)).to(F32) * fac
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):

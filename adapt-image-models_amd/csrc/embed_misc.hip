@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const aim_cast_desc* __
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long long)gridDim.y * 256) {
         const int r = (int)(i / d.C), c = (int)(i - (long long)r * d.C);
         const float v = src[i];
-        if (d.transpose) dst[(long long)c * d.ldd + r] = (bf16_t)v;
+        if (d.transpose == 2) ((float*)d.dst)[(long long)r * d.ldd + c] = v;       // fp32 copy (bias staging)
+        else if (d.transpose) dst[(long long)c * d.ldd + r] = (bf16_t)v;
         else dst[(long long)r * d.ldd + c] = (bf16_t)v;
     }
 }

@@ -11,13 +11,15 @@
 
 namespace {
 
-// one workgroup per sample: pooled row into LDS, then C dot products of length D (W rows read from L2)
+// workgroup (b, ct): the sample's pooled row into LDS (T*D floats: cheap enough to redo per class tile), then 32 classes,
+// a wave per class with coalesced 256-B reads of the weight row (L2-resident)
+constexpr int HEAD_CT = 32;
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ drop,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ pooled, float* __restrict__ score, int T,
                                                        int D, int C) {
     extern __shared__ float sx[];                 // [D]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, c0 = blockIdx.y * HEAD_CT, tid = threadIdx.x;
     const float invT = 1.0f / (float)T;
     for (int d = tid; d < D; d += 256) {
         float s = 0.f;
@@ -25,11 +27,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         s *= invT;
         if (drop) s *= drop[(long long)b * D + d];
         sx[d] = s;
-        pooled[(long long)b * D + d] = s;
+        if (blockIdx.y == 0) pooled[(long long)b * D + d] = s;
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < C; c += 4) {           // a wave per class: coalesced 256-B reads of the weight row
+    for (int c = c0 + wave; c < min(c0 + HEAD_CT, C); c += 4) {
         const float* w = W + (long long)c * D;
         float acc = 0.f;
         for (int d = lane; d < D; d += 64) acc += w[d] * sx[d];
@@ -103,21 +105,26 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     }
 }
 
-// dfeat[b][t][d] = drop[b][d] / T * sum_c dscore[b][c] W[c][d]     (grid: B blocks)
+// dfeat[b][t][d] = drop[b][d] / T * sum_c dscore[b][c] W[c][d]     (grid: B x ceil(D / 64); 4 class groups x 64 columns,
+// partial sums combined through LDS in a fixed order)
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dscore, const float* __restrict__ drop,
                                                          const float* __restrict__ W, float* __restrict__ dfeat, int T,
                                                          int D, int C) {
-    extern __shared__ float sg[];                 // [C]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float sg[];                 // [C] + [4][64]
+    float* part = sg + C;
+    const int b = blockIdx.x, tid = threadIdx.x, dl = tid & 63, grp = tid >> 6;
+    const int d = blockIdx.y * 64 + dl;
     for (int c = tid; c < C; c += 256) sg[c] = dscore[(long long)b * C + c];
     __syncthreads();
-    const float invT = 1.0f / (float)T;
-    for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += sg[c] * W[(long long)c * D + d];     // coalesced across the block
-        acc *= invT;
-        if (drop) acc *= drop[(long long)b * D + d];
-        for (int t = 0; t < T; ++t) dfeat[((long long)b * T + t) * D + d] = acc;
+    float acc = 0.f;
+    if (d < D)
+        for (int c = grp; c < C; c += 4) acc += sg[c] * W[(long long)c * D + d];     // 256-B coalesced per wave
+    part[grp * 64 + dl] = acc;
+    __syncthreads();
+    if (grp == 0 && d < D) {
+        float v = ((part[dl] + part[64 + dl]) + (part[128 + dl] + part[192 + dl])) / (float)T;
+        if (drop) v *= drop[(long long)b * D + d];
+        for (int t = 0; t < T; ++t) dfeat[((long long)b * T + t) * D + d] = v;
     }
 }
 
@@ -127,8 +134,8 @@ extern "C" int aim_head_fwd(const float* feat, const float* drop, const float* W
                             float* score, int B, int T, int D, int C, void* stream) {
     AIM_CHECK_ARG(feat && W && pooled && score && B > 0 && T > 0 && D > 0 && C > 0, "head_fwd: bad arguments");
     AIM_CHECK_ARG((size_t)D * 4 <= 64 * 1024, "head_fwd: D=%d too large", D);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)D * 4, (hipStream_t)stream, feat, drop, W, bias, pooled,
-                       score, T, D, C);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B, (C + HEAD_CT - 1) / HEAD_CT), dim3(256), (size_t)D * 4, (hipStream_t)stream, feat,
+                       drop, W, bias, pooled, score, T, D, C);
     AIM_CHECK_LAUNCH("aim_head_fwd");
     return 0;
 }
@@ -136,14 +143,14 @@ extern "C" int aim_head_fwd(const float* feat, const float* drop, const float* W
 extern "C" int aim_head_bwd(const float* dscore, const float* pooled, const float* drop, const float* W, float* dW,
                             float* db, float* dfeat, int B, int T, int D, int C, void* stream) {
     AIM_CHECK_ARG(dscore && pooled && W && B > 0 && T > 0 && D > 0 && C > 0, "head_bwd: bad arguments");
-    AIM_CHECK_ARG((size_t)C * 4 <= 64 * 1024, "head_bwd: C=%d too large", C);
+    AIM_CHECK_ARG((size_t)(C + 256) * 4 <= 64 * 1024, "head_bwd: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
     if (dW) {
         hipLaunchKernelGGL(head_wgrad_kernel, dim3(C), dim3(256), 0, st, dscore, pooled, dW, db, B, D, C);
         AIM_CHECK_LAUNCH("aim_head_bwd(wgrad)");
     }
     if (dfeat) {
-        hipLaunchKernelGGL(head_dgrad_kernel, dim3(B), dim3(256), (size_t)C * 4, st, dscore, drop, W, dfeat, T, D, C);
+        hipLaunchKernelGGL(head_dgrad_kernel, dim3(B, (D + 63) / 64), dim3(256), (size_t)(C + 256) * 4, st, dscore, drop, W, dfeat, T, D, C);
         AIM_CHECK_LAUNCH("aim_head_bwd(dgrad)");
     }
     return 0;

@@ -411,10 +411,10 @@ class CastTable:
         self.keep = entries            # keep the tensors alive: the table holds raw pointers
         raw = b"".join(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], dst.stride(0),
                                    int(tr)) for src, dst, tr in entries)
-        for src, dst, tr in entries:
-            _chk(src, F32, "src"); _chk(dst, BF16, "dst")
+        for src, dst, tr in entries:       # tr: False / True = bf16 cast (plain / transposed); 2 = fp32 copy
+            _chk(src, F32, "src"); _chk(dst, F32 if tr == 2 else BF16, "dst")
             assert src.dim() == 2 and src.is_contiguous()
-            assert tuple(dst.shape) == ((src.shape[1], src.shape[0]) if tr else tuple(src.shape))
+            assert tuple(dst.shape) == ((src.shape[1], src.shape[0]) if tr is True or tr == 1 else tuple(src.shape))
         self.n = len(entries)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.ptrs = tuple(src.data_ptr() for src, _, _ in entries)

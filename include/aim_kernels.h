@@ -232,7 +232,7 @@ int aim_add_rows_bf16(aim_bf16* dst, int64_t dst_row_stride, const float* src, i
  * lives in DEVICE memory (built once; the pointers are stable). */
 typedef struct aim_cast_desc {
     const float* src;   /* [R, C] dense fp32 */
-    aim_bf16* dst;      /* [R, ldd] or, transposed, [C, ldd] */
+    void* dst;          /* bf16 [R, ldd] or, transposed, [C, ldd]; transpose == 2: fp32 [R, ldd] plain copy */
     int32_t R, C, ldd, transpose;
 } aim_cast_desc;
 int aim_cast_multi(const aim_cast_desc* table_dev, int n, void* stream);

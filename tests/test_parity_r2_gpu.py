@@ -165,20 +165,23 @@ def test_backbone_droppath_tiny(golden_dir, monkeypatch):
     m, st = _model(32, T, 16, D, L, H, seed, drop=0.5)
     m.train()
     mk = z["masks"]
-    queue = [None, None, mk[0], mk[1], mk[2], mk[3]]        # two draws per block; layer 0 has rate 0 (vit_clip.py:297)
-    real = aim_amd.ViT_CLIP._drop_mask
+    real = m._drop_masks
+    calls = []
 
-    def fake(N, drop_prob, scale, training, dev):
-        mask = queue.pop(0)
-        if mask is None:
-            assert drop_prob == 0.0
-            return real(N, drop_prob, scale, training, dev)
-        assert training and drop_prob > 0
-        return (mask * scale).to(dev)
-    monkeypatch.setattr(aim_amd.ViT_CLIP, "_drop_mask", staticmethod(fake))
+    def fake(N, training, dev):
+        own = real(N, training, dev)                      # shape / layer-0 semantics come from the product
+        assert training and tuple(own.shape) == (L, 2, N)
+        assert torch.equal(own[0], torch.full((2, N), 0.5, device=dev))     # layer 0: rate 0 = Identity (vit_clip.py:297)
+        vals = sorted(set(own[2].flatten().tolist()))
+        assert vals[0] == 0.0 and abs(vals[-1] - 0.5 / 0.5) < 1e-6          # layer 2: rate 0.5 -> {0, scale / keep}
+        out = own.clone()
+        out[1, 0], out[1, 1], out[2, 0], out[2, 1] = [(mk[j] * 0.5).to(dev) for j in range(4)]
+        calls.append(1)
+        return out
+    monkeypatch.setattr(m, "_drop_masks", fake)
     y = m(z["imgs"].to(DEV))
     y.backward(z["g"].to(DEV))
-    assert not queue
+    assert len(calls) == 1
     names = O.trainable_names(st)
     for n in names:
         st[n] = st[n].detach().requires_grad_(True)

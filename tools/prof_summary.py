@@ -35,7 +35,7 @@ def main():
           f"(streams overlap, so the sum exceeds wall time).\n")
     print("Busy time per HIP stream (ms/step): " + ", ".join(f"stream {k}: {v / steps:.2f}" for k, v in sorted(busy.items())) + "\n")
     print("| kernel | calls/step | ms/step | avg us | % of kernel time |\n|---|---|---|---|---|")
-    for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+    for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
         print(f"| `{n}` | {v[0] / steps:.1f} | {v[1] / steps:.3f} | {v[1] / v[0] * 1e3:.1f} | {100 * v[1] / tot:.2f} |")
 
 
