@@ -191,14 +191,14 @@ def test_droppath_mask_semantics():
     assert np.allclose(dpr, np.linspace(0, 0.3, 4))
     # the whole model's factors in one draw: [L, 2, N], per layer {0, scale / keep} at its own rate, two independent rows
     mk = model._drop_masks(4000, True, torch.device(DEV))
-    assert tuple(mk.shape) == (4, 2, 4000) and torch.equal(mk[0], torch.full((2, 4000), 1.0, device=DEV))   # scale 1, rate 0
+    assert tuple(mk.shape) == (4, 2, 4000) and torch.equal(mk[0], torch.full((2, 4000), 0.5, device=DEV))   # adapter_scale 0.5, rate 0
     for l in (1, 2, 3):
         keep = 1 - dpr[l]
         vals = sorted(mk[l].unique().cpu().tolist())
-        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / keep) < 1e-6
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 0.5 / keep) < 1e-6
         assert abs((mk[l] > 0).float().mean().item() - keep) < 0.03
         assert not torch.equal(mk[l, 0], mk[l, 1])
-    assert torch.equal(model._drop_masks(7, False, torch.device(DEV)), torch.ones((4, 2, 7), device=DEV))
+    assert torch.equal(model._drop_masks(7, False, torch.device(DEV)), torch.full((4, 2, 7), 0.5, device=DEV))
 
 
 def test_full_size_properties():
