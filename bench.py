@@ -317,17 +317,20 @@ def main():
                 # HBM-side bytes per launch of that kernel: NOT measured in this run -- read from the committed PMC
                 # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, profiles/)
                 traffic, traffic_src = None, None
-                for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+                mfma_busy = None
+                for name in ("r02_gemm_pmc.json", "r01_gemm_traffic.json"):
                     try:
-                        tj = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
-                        traffic = round(tj["gemm256_kernel<%d>" % dom]["hbm_bytes_per_launch"])
-                        traffic_src = "profiles/" + name + " (committed PMC passes, not this run)"
+                        tj = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["gemm256_kernel<%d>" % dom]
+                        traffic = round(tj["hbm_bytes_per_launch"])
+                        mfma_busy = tj.get("mfma_busy_frac")
+                        traffic_src = "profiles/" + name + " (committed rocprofv3 PMC passes of this command, not measured in this run)"
                         break
                     except Exception:
                         pass
                 roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "traffic_source": traffic_src,
+                        "mfma_busy_frac_pmc": None if mfma_busy is None else round(mfma_busy, 4),
                         "launches_per_step": d["launches"] / args.steps,
                         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "flops_per_launch": d["flops"] / d["launches"],
