@@ -548,12 +548,26 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         ops.gemm_fp8(hcat, f8.Wcat2, f8.s2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
         return x2, None
     ops.gemm(ao, fz.Wo, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
-    # joint adaptation (:285-286)
+    x2, xn, mean2, rstd2, hcat_pre, a_s = _mlp_adapter_forward(x1, fz, dms2, N, save)
+    ctx = None
+    if save:
+        ctx = dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, probs=probs, ta=ta, t_pre=t_pre, t_h=t_h, lam=lam,
+                   oml=oml, ao=ao, lse=lse, sin=sin, s_pre=s_pre, s_h=s_h, x1=x1, mean2=mean2, rstd2=rstd2, xn=xn,
+                   hcat_pre=hcat_pre, a_s=a_s, dms1=dms1, dms2=dms2)
+    return x2, ctx
+
+
+def _mlp_adapter_forward(x1, fz: _Frozen, dms2, N, save: bool):
+    """Joint adaptation (vit_clip.py:285-286; identical in vitclip_aim.py:209-210): x2 = x1 + mlp(ln_2(x1)) +
+    drop_path(scale * MLP_Adapter(ln_2(x1))).  One GEMM for [c_fc | D_fc1] (N = 4D + r; QuickGELU on the MLP columns,
+    dms2 * GELU on the adapter's) and one for [c_proj | D_fc2] (K = 4D + r); the adapter's token-scaled bias rides along
+    as `vec`.  Returns (x2, xn, mean2, rstd2, hcat_pre, a_s)."""
+    dev = x1.device
+    M, D = x1.shape
+    r, H4 = fz.r, 4 * D
     xn = _empty((M, D), BF16, dev)
     mean2, rstd2 = _empty((M,), F32, dev), _empty((M,), F32, dev)
     ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
-    # one GEMM for [c_fc | D_fc1] (N = 4D + r; QuickGELU on the MLP columns, dms2 * GELU on the adapter's)
-    # and one for [c_proj | D_fc2] (K = 4D + r); the adapter's token-scaled bias rides along as `vec`.
     hcat_pre, hcat = _empty((M, H4 + r), BF16, dev), _empty((M, H4 + r), BF16, dev)
     ops.gemm(xn, fz.Wcat1, ops.EPI_ACT, hcat, bias=fz.bcat1, out2=hcat_pre, act=ops.ACT_QGELU, n_split=H4,
              act2=ops.ACT_GELU, at=dms2, ntok=N)
@@ -562,13 +576,34 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     # the adapter's activation slice stays a VIEW of hcat (wgrad takes a row stride): no copy kernel in the forward, at the
     # price of keeping hcat (M x (4D + r) bf16) alive until this block's backward
     a_s = hcat[:, H4:] if save else None
-    del hcat
-    ctx = None
-    if save:
-        ctx = dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, probs=probs, ta=ta, t_pre=t_pre, t_h=t_h, lam=lam,
-                   oml=oml, ao=ao, lse=lse, sin=sin, s_pre=s_pre, s_h=s_h, x1=x1, mean2=mean2, rstd2=rstd2, xn=xn,
-                   hcat_pre=hcat_pre, a_s=a_s, dms1=dms1, dms2=dms2)
-    return x2, ctx
+    return x2, xn, mean2, rstd2, hcat_pre, a_s
+
+
+def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: _Frozen, gm, N):
+    """Backward of ``_mlp_adapter_forward``: returns (d(x_in) as bf16, the weight-gradient closures).  x2 = x_in +
+    [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2."""
+    dev = dyb.device
+    M, D = dyb.shape
+    r, H4 = fz.r, 4 * D
+    big_later: list = []
+    if _DETACH_BIG:
+        big_later.append(lambda: ops.colsum(dyb, gm["D_fc2.bias"], at=dms2, ntok=N))
+        big_later.append(lambda: ops.wgrad(dyb, a_s, gm["D_fc2.weight"]))
+    else:
+        ops.colsum(dyb, gm["D_fc2.bias"], at=dms2, ntok=N)
+        ops.wgrad(dyb, a_s, gm["D_fc2.weight"])
+    dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
+    ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=hcat_pre, act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
+             at=dms2, ntok=N)
+    if _DETACH_BIG:
+        big_later.append(lambda: ops.wgrad(dcat[:, H4:], xn, gm["D_fc1.weight"], gm["D_fc1.bias"]))
+    else:
+        ops.wgrad(dcat[:, H4:], xn, gm["D_fc1.weight"], gm["D_fc1.bias"])
+    dxn = _empty((M, D), BF16, dev)
+    ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
+    dxb = _empty((M, D), BF16, dev)                  # (dcat stays alive in the D_fc1 weight-gradient closure)
+    ops.layernorm_bwd(dxn, x_in, fz.g2, mean2, rstd2, M, D, lddy=D, ldx=D, lddx=D, dres=dyb, dx_bf16=dxb)
+    return dxb, big_later
 
 
 def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, ar: _Arena, need_dx_bf16: bool, later: list):
@@ -593,31 +628,8 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     M, D = dyb.shape
     BT = B * T
     r, H4 = fz.r, 4 * D
-    gm = grads["MLP_Adapter"]
-    # ---- MLP + MLP_Adapter: x2 = x1 + [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2
-    big_later: list = []
-    if _DETACH_BIG:
-        a_s_, dms2_, xn_ = c["a_s"], c["dms2"], c["xn"]
-        big_later.append(lambda: ops.colsum(dyb, gm["D_fc2.bias"], at=dms2_, ntok=N))
-        big_later.append(lambda: ops.wgrad(dyb, a_s_, gm["D_fc2.weight"]))
-    else:
-        ops.colsum(dyb, gm["D_fc2.bias"], at=c["dms2"], ntok=N)
-        ops.wgrad(dyb, c["a_s"], gm["D_fc2.weight"])
-    dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
-    ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=c["hcat_pre"], act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
-             at=c["dms2"], ntok=N)
-    if _DETACH_BIG:
-        dcat_ = dcat
-        big_later.append(lambda: ops.wgrad(dcat_[:, H4:], xn_, gm["D_fc1.weight"], gm["D_fc1.bias"]))
-    else:
-        ops.wgrad(dcat[:, H4:], c["xn"], gm["D_fc1.weight"], gm["D_fc1.bias"])
-    dxn = _empty((M, D), BF16, dev)
-    ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
-    del dcat
-    # ---- ln_2
-    dx1b = _empty((M, D), BF16, dev)
-    ops.layernorm_bwd(dxn, c["x1"], fz.g2, c["mean2"], c["rstd2"], M, D, lddy=D, ldx=D, lddx=D, dres=dyb, dx_bf16=dx1b)
-    del dxn
+    dx1b, big_later = _mlp_adapter_backward(dyb, c["x1"], c["mean2"], c["rstd2"], c["xn"], c["hcat_pre"], c["a_s"], c["dms2"],
+                                            fz, grads["MLP_Adapter"], N)
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
     later: list = big_later       # the adapters' weight gradients: nobody downstream waits for them
@@ -723,12 +735,20 @@ class _BackboneFn(torch.autograd.Function):
         # blocks
         ctxs: List[Optional[dict]] = []
         training = model.training
-        f8 = model._fp8_operands() if (model.inference_precision == 'fp8' and not need_grad and M >= 1024) else None
+        f8 = model._fp8_operands() if (model.inference_precision == 'fp8' and not need_grad and M >= 1024
+                                       and model.variant == 'vit_clip') else None
         masks = model._drop_masks(N, training, dev)          # [L, 2, N]: all layers' DropPath factors in three launches
+        aim = model.variant == 'aim'
+        if aim:
+            from .aim_variant import aim_block_forward
         for i in range(L):
             dms1, dms2 = masks[i, 0], masks[i, 1]
-            x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad,
-                                  f8=None if f8 is None else f8[i])
+            if aim:      # stock-AIM block: its first DropPath acts on the un-scaled temporal branch (vitclip_aim.py:205)
+                scale = float(model.transformer.resblocks[i].scale)
+                x, c = aim_block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1 * (1.0 / scale), dms2, need_grad)
+            else:
+                x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad,
+                                      f8=None if f8 is None else f8[i])
             ctxs.append(c)
         # ln_post on the class rows only (LayerNorm is per-row; vit_clip.py:452-453)
         gw, gb = lnp_w.detach().float().contiguous(), lnp_b.detach().float().contiguous()
@@ -784,8 +804,11 @@ class _BackboneFn(torch.autograd.Function):
                           dx_bf16=dxb, dgamma=dgw, dbeta=dgb)
         keep: list = []        # tensors the detached weight-gradient stream still reads; dropped after join_detached
         hook = model.grad_ready_hook
+        blk_bwd = _block_backward
+        if model.variant == 'aim':
+            from .aim_variant import aim_block_backward as blk_bwd
         for i in reversed(range(L)):
-            dxb = _block_backward(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
+            dxb = blk_bwd(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
             s["ctxs"][i] = None
             if hook is not None:
                 # every kernel that accumulates into the gradients of layers >= i has been QUEUED (adapter weight
@@ -841,6 +864,7 @@ class ViT_CLIP(nn.Module):
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
         self.grad_ready_hook = None                 # fn(layer, in_place, streams): set by dist.FlatAdamW (overlapped all-reduce)
         self._fp8_cache = None
+        self.variant = 'vit_clip'                   # 'aim': the stock-AIM block (aim_variant.py)
         # inference precision of the large GEMMs: 'bf16' (default, the training kernels) or 'fp8' (BASELINE configs[4]:
         # fp8 e4m3 operands on the block-scaled MFMA; no-grad forwards only).  AIM_INFER_FP8=1 selects fp8 globally.
         self.inference_precision = 'fp8' if os.environ.get("AIM_INFER_FP8", "0") == "1" else 'bf16'

@@ -56,6 +56,10 @@ SIGNATURES = {
     "aim_attn_bwd": [P, P, P, P, P, P, I, I, I, P],
     "aim_cls_attn_fwd": [P, P, P, I, I, I, I, P],
     "aim_cls_attn_bwd": [P, P, P, P, I, I, I, I, I, P],
+    "aim_tattn_fwd": [P, P, P, I, I, I, I, P],
+    "aim_tattn_bwd": [P, P, P, P, I, I, I, I, P],
+    "aim_add_bf16": [P, L, P, L, P, L, I, I, P],
+    "aim_acc_bf16": [P, P, L, I, I, P],
     "aim_lambda_partials": [P, P, P, I, P],
     "aim_qk_cross": [P, P, I, P, I, I, I, F, P],
     "aim_lambda": [P, P, I, P, P, I, P, P, I, I, I, F, P],

@@ -255,6 +255,35 @@ def cls_attn_bwd(qkv, probs, dout_cls, dqkv, B, T, N, H, compact: bool = False):
                                           int(compact), B, T, N, H, _stream()), "aim_cls_attn_bwd")
 
 
+def tattn_fwd(qkv, out, probs, B, T, N, H):
+    """Temporal attention over the T frames of every token position (stock-AIM block): out [M, D], probs [B*N, H, T, T]."""
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(probs, F32, "probs")
+    check(load_library().aim_tattn_fwd(qkv.data_ptr(), out.data_ptr(), probs.data_ptr(), B, T, N, H, _stream()), "aim_tattn_fwd")
+
+
+def tattn_bwd(qkv, probs, dout, dqkv, B, T, N, H):
+    _chk(qkv, BF16, "qkv"); _chk(probs, F32, "probs"); _chk(dout, BF16, "dout"); _chk(dqkv, BF16, "dqkv")
+    check(load_library().aim_tattn_bwd(qkv.data_ptr(), probs.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, T, N, H, _stream()),
+          "aim_tattn_bwd")
+
+
+def add_bf16(a, b, out):
+    """out = a + b (bf16, 2-D, row-strided)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, BF16, "out")
+    R, C = a.shape
+    check(load_library().aim_add_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), R, C,
+                                      _stream()), "aim_add_bf16")
+    return out
+
+
+def acc_bf16(x, s):
+    """x (f32, dense 2-D) += s (bf16, row-strided)."""
+    _chk(x, F32, "x"); _chk(s, BF16, "s")
+    assert x.is_contiguous() and x.shape == s.shape
+    check(load_library().aim_acc_bf16(x.data_ptr(), s.data_ptr(), s.stride(0), x.shape[0], x.shape[1], _stream()), "aim_acc_bf16")
+    return x
+
+
 def lambda_partials(partials, lam, one_minus, BT):
     """lamda from [BT, 16, 2] (max, sum) slots: 8 ``ow`` partials, 8 ``cw`` partials (EXPSUM GEMM with ``xrow``)."""
     _chk(partials, F32, "partials"); _chk(lam, F32, "lam"); _chk(one_minus, F32, "one_minus")

@@ -133,8 +133,10 @@ def register_into_mmaction() -> bool:
         from mmaction.models.builder import BACKBONES as MB   # type: ignore
     except Exception:
         return False
+    from .aim_variant import AIM
     from .backbone import ViT_CLIP
     MB.register_module(name="ViT_CLIP", force=True, module=ViT_CLIP)
+    MB.register_module(name="AIM", force=True, module=AIM)       # stock AIM (vitclip_aim.py:353), wind_attn=False
     return True
 
 

@@ -173,6 +173,21 @@ int aim_cls_attn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* do
                      int B, int T, int N, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Temporal attention over the T frames of EVERY token position -- the stock-AIM block
+ * (mmaction/models/backbones/vitclip_aim.py:199-205: attention() :148-187 on 'n (b t) d -> t (b n) d', seq = T, batch = B*N).
+ *   qkv [B*T*N, 3*D] bf16 frame-major ; out [B*T*N, D] bf16 ; probs [B*N, H, T, T] f32 (saved for backward)
+ *   bwd WRITES dqkv [B*T*N, 3*D] bf16.
+ * aim_add_bf16: out = a + b (bf16, row strides) ; aim_acc_bf16: x (f32, dense) += s (bf16): the residual adds of that
+ * block's S_Adapter branch (skip_connect=True, :211) that no GEMM epilogue of this library covers.
+ * ------------------------------------------------------------------------------------------ */
+int aim_tattn_fwd(const aim_bf16* qkv, aim_bf16* out, float* probs, int B, int T, int N, int H, void* stream);
+int aim_tattn_bwd(const aim_bf16* qkv, const float* probs, const aim_bf16* dout, aim_bf16* dqkv, int B, int T, int N, int H,
+                  void* stream);
+int aim_add_bf16(const aim_bf16* a, int64_t lda, const aim_bf16* b, int64_t ldb, aim_bf16* out, int64_t ldo, int R, int C,
+                 void* stream);
+int aim_acc_bf16(float* x, const aim_bf16* s, int64_t lds, int R, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * lamda = cw / (cw + ow) per frame -- vit_clip.py:149-151, 184-186, 272.
  *   ow[bt] = sum_{i,j} exp(q_i . k_j / 8)  arrives as AIM_EPI_EXPSUM partial pairs
  *            partials [BT, ntiles, 2];  cw[bt] = sum_i exp(q_i . kx[bt] / 8) is computed here.

@@ -213,6 +213,52 @@ def ref_block(x: Tensor, st: State, i: int, heads: int, num_frames: int, scale: 
     return x
 
 
+def ref_aim_block(x: Tensor, st: State, i: int, heads: int, num_frames: int, scale: float,
+                  drop_mask=None) -> Tensor:
+    """Stock-AIM ``ResidualAttentionBlock.forward``, ``wind_attn=False``, ``num_tadapter=1``
+    (``mmaction/models/backbones/vitclip_aim.py:195-211``): temporal attention over the T frames of EVERY token
+    position -> T_Adapter (no skip) -> DropPath; spatial attention -> S_Adapter WITH skip connection (``:124``,
+    ``Adapter`` default ``skip_connect=True`` ``:76,93-96``), no scale, no DropPath; MLP + DropPath(scale * MLP_Adapter).
+    ``x``: ``[N, BT, D]``; ``drop_mask``: None or the pair of ``[N]`` factors the block's two ``drop_path`` calls drew."""
+    pre = f"transformer.resblocks.{i}."
+    n, bt, d = x.shape
+    T = num_frames
+    dm1, dm2 = drop_mask if isinstance(drop_mask, (tuple, list)) else (drop_mask, drop_mask)
+    dp1 = (lambda t: t) if dm1 is None else (lambda t: t * dm1.reshape(-1, 1, 1))
+    dp2 = (lambda t: t) if dm2 is None else (lambda t: t * dm2.reshape(-1, 1, 1))
+    ln1 = lambda t: ref_layer_norm(t, st[pre + "ln_1.weight"], st[pre + "ln_1.bias"])
+    # temporal adaptation (:199-205): 'n (b t) d -> t (b n) d'
+    xt = x.reshape(n, bt // T, T, d).permute(2, 1, 0, 3).reshape(T, (bt // T) * n, d)
+    xt = ref_adapter(ref_attention(ln1(xt), ln1(xt), st, pre, heads), st, pre + "T_Adapter")
+    xt = xt.reshape(T, bt // T, n, d).permute(2, 1, 0, 3).reshape(n, bt, d)      # 't (b n) d -> n (b t) d'
+    x = x + dp1(xt)
+    # spatial adaptation (:207): S_Adapter(y) = y + D_fc2(GELU(D_fc1(y)))
+    sa = ref_attention(ln1(x), ln1(x), st, pre, heads)
+    x = x + sa + ref_adapter(sa, st, pre + "S_Adapter")
+    # joint adaptation (:209-210)
+    xn = ref_layer_norm(x, st[pre + "ln_2.weight"], st[pre + "ln_2.bias"])
+    h = F.linear(xn, st[pre + "mlp.c_fc.weight"], st[pre + "mlp.c_fc.bias"])
+    h = F.linear(ref_quick_gelu(h), st[pre + "mlp.c_proj.weight"], st[pre + "mlp.c_proj.bias"])
+    return x + h + dp2(scale * ref_adapter(xn, st, pre + "MLP_Adapter"))
+
+
+def ref_aim_backbone(imgs: Tensor, st: State, heads: int, num_frames: int, scale: float = 0.5,
+                     layers: Optional[int] = None, drop_masks=None) -> Tensor:
+    """``AIM.forward`` (``vitclip_aim.py:468-493``): the embedding / ln_pre / ln_post / class-token readout are the
+    same statements as ``vit_clip.py:433-458``; only the block differs."""
+    B, _, T = imgs.shape[:3]
+    if layers is None:
+        layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
+    x = ref_embed(imgs, st, num_frames)
+    for i in range(layers):
+        x = ref_aim_block(x, st, i, heads, num_frames, scale, drop_mask=None if drop_masks is None else drop_masks[i])
+    x = x.permute(1, 0, 2)
+    x = ref_layer_norm(x, st["ln_post.weight"], st["ln_post.bias"])
+    x = x[:, 0]
+    x = x.reshape(B, T, -1).permute(0, 2, 1)
+    return x.unsqueeze(-1).unsqueeze(-1)
+
+
 def ref_embed(imgs: Tensor, st: State, num_frames: int) -> Tensor:
     """``ViT_CLIP.forward`` up to ``ln_pre`` (``vit_clip.py:433-449``) -> ``[N, BT, D]``."""
     B, C, T, H, W = imgs.shape
@@ -427,6 +473,69 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
         # ow/cw are reported un-shifted only through their ratio; lam is the contract
         return x2, dict(lamda=lam, xt=xt, ow_shifted=ow, cw_shifted=cw, shift=m)
     return x2
+
+
+def emu_aim_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float, rnd: Rounding = FP32,
+                  drop_mask=None) -> Tensor:
+    """Stock-AIM block in the product's frame-major dataflow ``[BT, N, D]`` with the product's bf16 rounding points."""
+    pre = f"transformer.resblocks.{i}."
+    BT, N, D = x.shape
+    B = BT // T
+    dh = D // heads
+    W, bqkv = st[pre + "attn.in_proj_weight"], st[pre + "attn.in_proj_bias"]
+    Wo, bo = st[pre + "attn.out_proj.weight"], st[pre + "attn.out_proj.bias"]
+    d1, d2 = drop_mask if isinstance(drop_mask, (tuple, list)) else (drop_mask, drop_mask)
+    dm1 = 1.0 if d1 is None else d1.reshape(1, N, 1)
+    dm2 = 1.0 if d2 is None else d2.reshape(1, N, 1)
+    ln1 = lambda t: rnd(F.layer_norm(t, (D,), st[pre + "ln_1.weight"], st[pre + "ln_1.bias"], 1e-5))
+
+    def attn(q, k, v):          # [..., S, heads*dh] over the second-to-last axis
+        sh = q.shape[:-1]
+        qh, kh, vh = (t.reshape(*sh, heads, dh).transpose(-2, -3) for t in (q, k, v))
+        p = ((qh @ kh.transpose(-1, -2)) / math.sqrt(dh)).softmax(-1)
+        return (p @ vh).transpose(-2, -3).reshape(*sh, heads * dh)
+
+    # temporal: sequence = frames, batch = (clip, token)
+    qkv = rnd(_lin(ln1(x), W, bqkv, rnd)).reshape(B, T, N, 3 * D).permute(0, 2, 1, 3)      # [B, N, T, 3D]
+    ot = rnd(attn(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]))                     # [B, N, T, D]
+    ot = ot.permute(0, 2, 1, 3).reshape(BT, N, D)
+    ta = rnd(_lin(ot, Wo, bo, rnd))
+    tp = pre + "T_Adapter"
+    t_pre = rnd(_lin(ta, st[tp + ".D_fc1.weight"], st[tp + ".D_fc1.bias"], rnd))
+    t_hs = rnd(dm1 * F.gelu(t_pre))                        # DropPath factor folded into the stored activation
+    x1 = x + _lin(t_hs, st[tp + ".D_fc2.weight"], None, rnd) + dm1 * st[tp + ".D_fc2.bias"]
+    # spatial, S_Adapter with skip
+    qkv2 = rnd(_lin(ln1(x1), W, bqkv, rnd))
+    q, k, v = qkv2[..., :D], qkv2[..., D:2 * D], qkv2[..., 2 * D:]
+    qh = q.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(BT, N, heads, dh).permute(0, 2, 1, 3)
+    sc = (qh @ kh.transpose(-1, -2)) / math.sqrt(dh)
+    pu = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    ao = rnd(((rnd(pu) @ vh) / pu.sum(dim=-1, keepdim=True)).permute(0, 2, 1, 3).reshape(BT, N, D))
+    sa = rnd(_lin(ao, Wo, bo, rnd))
+    x2 = x1 + sa + emu_adapter(sa, st, pre + "S_Adapter", rnd)
+    # MLP + MLP_Adapter (as the vit_clip block)
+    xn = rnd(F.layer_norm(x2, (D,), st[pre + "ln_2.weight"], st[pre + "ln_2.bias"], 1e-5))
+    hpre = rnd(_lin(xn, st[pre + "mlp.c_fc.weight"], st[pre + "mlp.c_fc.bias"], rnd))
+    h = rnd(ref_quick_gelu(hpre))
+    mlp = _lin(h, st[pre + "mlp.c_proj.weight"], st[pre + "mlp.c_proj.bias"], rnd)
+    mp = pre + "MLP_Adapter"
+    a_pre = rnd(_lin(xn, st[mp + ".D_fc1.weight"], st[mp + ".D_fc1.bias"], rnd))
+    a_s = rnd(dm2 * scale * F.gelu(a_pre))
+    return x2 + mlp + _lin(a_s, st[mp + ".D_fc2.weight"], None, rnd) + dm2 * scale * st[mp + ".D_fc2.bias"]
+
+
+def emu_aim_backbone(imgs: Tensor, st: State, heads: int, scale: float = 0.5, rnd: Rounding = FP32,
+                     layers: Optional[int] = None, drop_masks=None) -> Tensor:
+    B, _, T = imgs.shape[:3]
+    if layers is None:
+        layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
+    x = emu_embed(imgs, st, rnd)
+    for i in range(layers):
+        x = emu_aim_block(x, st, i, heads, T, scale, rnd, drop_mask=None if drop_masks is None else drop_masks[i])
+    c = F.layer_norm(x[:, 0], (x.shape[-1],), st["ln_post.weight"], st["ln_post.bias"], 1e-5)
+    return c.reshape(B, T, -1).permute(0, 2, 1).unsqueeze(-1).unsqueeze(-1)
 
 
 def emu_embed(imgs: Tensor, st: State, rnd: Rounding = FP32) -> Tensor:

@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from oracle import vit_clip_oracle as O  # noqa: E402
 
 REF = "/root/reference/mmaction/models/backbones/vit_clip.py"
+REF_AIM = "/root/reference/mmaction/models/backbones/vitclip_aim.py"
 
 
 def load_reference():
@@ -74,6 +75,44 @@ def load_reference():
     sys.modules[spec.name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_aim():
+    """The stock-AIM file (class ``AIM``); same stand-ins as ``load_reference`` (call that first)."""
+    spec = importlib.util.spec_from_file_location("mmaction.models.backbones.vitclip_aim", REF_AIM)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_aim(mod_aim, T, seed, train):
+    """Whole tiny stock-AIM backbone (``AIM(..., wind_attn=False)``, 3 layers): output + all trainable gradients; in
+    train mode with the DropPath masks the reference drew (two per block with rate > 0)."""
+    D, H, L, B = 128, 2, 3, 2
+    logging.getLogger("ref").setLevel(logging.ERROR)
+    m = mod_aim.AIM(32, T, 16, D, L, H, drop_path_rate=0.5 if train else 0.0, adapter_scale=0.5, wind_attn=False)
+    m.init_weights()
+    st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, L), seed=seed)
+    msg = m.load_state_dict(st, strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    m.train() if train else m.eval()
+    imgs = randn((B, 3, T, 32, 32), seed + 1)
+    g = randn((B, D, T, 1, 1), seed + 2)
+    torch.manual_seed(seed + 9)
+    del _drawn()[:]
+    y = m(imgs)
+    masks = list(_drawn())
+    params = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    assert sorted(params) == sorted(O.trainable_names(st))
+    grads = torch.autograd.grad(y, list(params.values()), g)
+    out = dict(imgs=imgs, g=g, y=y, meta=np.array([D, H, L, B, T, seed]))
+    if train:
+        assert len(masks) == 4 and any((k == 0).any() for k in masks)
+        out["masks"] = torch.stack(masks)
+    for (n, _), gr in zip(params.items(), grads):
+        out["grad." + n] = gr
+    np.savez_compressed(os.path.join(HERE, f"aim_backbone_tiny_T{T}{'_droppath' if train else ''}.npz"), **npify(out))
 
 
 def randn(shape, seed):
@@ -246,6 +285,11 @@ def gen_cfg1(mod, seed):
 def main():
     torch.set_num_threads(8)
     mod = load_reference()
+    if "--aim-only" in sys.argv:            # stock-AIM variant (vitclip_aim.py), round 2
+        aim = load_reference_aim()
+        gen_aim(aim, 2, 1100, False)
+        gen_aim(aim, 4, 1200, True)
+        return
     if "--droppath-only" in sys.argv:       # round 2 additions; the round-1 fixtures stay byte-identical
         gen_block_droppath(mod, 2, 700)
         gen_block_droppath(mod, 4, 800)

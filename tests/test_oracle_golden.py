@@ -221,3 +221,29 @@ def test_backbone_droppath_tiny(golden_dir):
         grads = torch.autograd.grad(y, [st[n] for n in names], z["g"])
         for n, g in zip(names, grads):
             _close(g, z["grad." + n], 2e-5, rel=5e-5)
+
+
+# ---- stock-AIM variant (mmaction/models/backbones/vitclip_aim.py, class AIM, wind_attn=False): SURVEY 8f-4 -----------
+@pytest.mark.parametrize("name,train", [("aim_backbone_tiny_T2.npz", False), ("aim_backbone_tiny_T4_droppath.npz", True)])
+def test_aim_backbone_tiny(golden_dir, name, train):
+    z = _load(golden_dir, name)
+    D, H, L, B, T, seed = [int(v) for v in z["meta"]]
+    st = O.synth_state_dict(O.backbone_param_shapes(32, T, 16, D, L), seed=seed)
+    names = O.trainable_names(st)
+    masks = None
+    if train:
+        mk = z["masks"]
+        assert any((k == 0).any() for k in mk)
+        masks = [None, (mk[0], mk[1]), (mk[2], mk[3])]
+    for fn in (lambda: O.ref_aim_backbone(z["imgs"], st, H, T, drop_masks=masks),
+               lambda: O.emu_aim_backbone(z["imgs"], st, H, drop_masks=masks)):
+        for n in names:
+            st[n] = st[n].detach().requires_grad_(True)
+        y = fn()
+        assert tuple(y.shape) == (B, D, T, 1, 1)
+        _close(y, z["y"], 2e-5)
+        grads = torch.autograd.grad(y, [st[n] for n in names], z["g"])
+        for n, g in zip(names, grads):
+            _close(g, z["grad." + n], 2e-5, rel=5e-5)
+    # it is a different network from vit_clip.py's block on the same weights
+    assert (O.ref_backbone(z["imgs"], st, H, T).detach() - z["y"]).abs().max() > 1e-2
