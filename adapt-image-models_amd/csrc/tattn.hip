@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const bf16_t* __restrict
                                                         float* __restrict__ probs, int B, int T, int N, int H) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long prob = (long long)blockIdx.x * 4 + wave;          // (b, n, h)
+    const long long prob = (long long)blockIdx.x * (blockDim.x >> 6) + wave;          // (b, n, h)
     const long long nprob = (long long)B * N * H;
     if (prob >= nprob) return;          // (whole waves only: no barrier below spans waves)
     const int h = (int)(prob % H);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16_t* __restrict
                                                         int T, int N, int H) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long prob = (long long)blockIdx.x * 4 + wave;
+    const long long prob = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
     const long long nprob = (long long)B * N * H;
     if (prob >= nprob) return;
     const int h = (int)(prob % H);
@@ -171,13 +171,14 @@ extern "C" int aim_tattn_fwd(const aim_bf16* qkv, aim_bf16* out, float* probs, i
     AIM_CHECK_ARG(B > 0 && T > 0 && T <= TMAX && N > 0 && H > 0, "tattn_fwd: unsupported shape B=%d T=%d (T <= 32)", B, T);
     AIM_CHECK_ARG(qkv && out && probs, "tattn_fwd: null pointer");
     const long long nprob = (long long)B * N * H;
-    const size_t lds = (size_t)4 * (3 * T * 65 + T * (T + 1)) * 4;
+    const int wpb = T <= 16 ? 4 : 2;                // waves (problems) per workgroup: LDS per problem grows with T
+    const size_t lds = (size_t)wpb * (3 * T * 65 + T * (T + 1)) * 4;
     static bool attr_set_f = false;
     if (!attr_set_f) {
         (void)hipFuncSetAttribute((const void*)tattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set_f = true;
     }
-    hipLaunchKernelGGL(tattn_fwd_kernel, dim3((unsigned)((nprob + 3) / 4)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(tattn_fwd_kernel, dim3((unsigned)((nprob + wpb - 1) / wpb)), dim3(64 * wpb), lds, (hipStream_t)stream, (const bf16_t*)qkv,
                        (bf16_t*)out, probs, B, T, N, H);
     AIM_CHECK_LAUNCH("aim_tattn_fwd");
     return 0;
@@ -188,13 +189,14 @@ extern "C" int aim_tattn_bwd(const aim_bf16* qkv, const float* probs, const aim_
     AIM_CHECK_ARG(B > 0 && T > 0 && T <= TMAX && N > 0 && H > 0, "tattn_bwd: unsupported shape B=%d T=%d (T <= 32)", B, T);
     AIM_CHECK_ARG(qkv && probs && dout && dqkv, "tattn_bwd: null pointer");
     const long long nprob = (long long)B * N * H;
-    const size_t lds = (size_t)4 * (4 * T * 65 + 2 * T * (T + 1)) * 4;
+    const int wpb = T <= 16 ? 4 : 2;
+    const size_t lds = (size_t)wpb * (4 * T * 65 + 2 * T * (T + 1)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)tattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)((nprob + 3) / 4)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)((nprob + wpb - 1) / wpb)), dim3(64 * wpb), lds, (hipStream_t)stream, (const bf16_t*)qkv,
                        probs, (const bf16_t*)dout, (bf16_t*)dqkv, B, T, N, H);
     AIM_CHECK_LAUNCH("aim_tattn_bwd");
     return 0;
