@@ -248,6 +248,7 @@ _LAMBDA_FUSED = os.environ.get("AIM_LAMBDA_FUSED", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
+_DETACHED_PRIORITY = int(os.environ.get("AIM_DETACHED_PRIORITY", "0"))   # HIP stream priority of the weight-gradient stream
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
 
@@ -338,7 +339,7 @@ class _Fork:
             return
         key = (self.dev.type, self.dev.index)
         if key not in _DETACHED:
-            _DETACHED[key] = torch.cuda.Stream(device=self.dev)
+            _DETACHED[key] = torch.cuda.Stream(device=self.dev, priority=_DETACHED_PRIORITY)
         w = _DETACHED[key]
         ev = torch.cuda.Event()
         ev.record(self.side_stream)
@@ -356,7 +357,7 @@ class _Fork:
             return None
         key = (self.dev.type, self.dev.index)
         if key not in _DETACHED:
-            _DETACHED[key] = torch.cuda.Stream(device=self.dev)
+            _DETACHED[key] = torch.cuda.Stream(device=self.dev, priority=_DETACHED_PRIORITY)
         w = _DETACHED[key]
         ev = torch.cuda.Event()
         ev.record(self.main)

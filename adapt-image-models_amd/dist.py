@@ -133,11 +133,17 @@ class FlatAdamW:
         self._sync = True
         self._comm = None
         self.early_launches = 0      # diagnostics: collectives started from inside backward
+        self.force_collectives = False
 
     # ---- overlapped all-reduce ---------------------------------------------------------------------------------
     @staticmethod
     def _world():
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _active(self):
+        """Collectives are issued when there is more than one rank -- or, for tests that must drive the real RCCL call
+        pattern on a one-GPU box, when ``force_collectives`` is set on an initialised single-rank group."""
+        return self._world() > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
 
     def attach_backbone(self, backbone, prefix_of=None, n_buckets: int = 3):
         """Plan early buckets over the flat buffer from the backbone's layer order and install its
@@ -171,7 +177,7 @@ class FlatAdamW:
             self._sync = old
 
     def _on_layer_queued(self, layer: int, in_place: bool, streams):
-        if not self._sync or self._world() == 1 or not in_place:
+        if not self._sync or not self._active() or not in_place:
             return
         for lo, a, b in self._buckets:
             if lo == layer and (a, b) not in self._reduced:
@@ -200,7 +206,7 @@ class FlatAdamW:
         """Finish the step's gradient reduction (SUM over ranks; the mean's 1/world is applied inside ``step``): reduce
         whatever the early buckets did not cover -- everything, when no backbone is attached -- and make the current
         stream wait for all of it."""
-        if self._world() == 1 or not self._sync:
+        if not self._active() or not self._sync:
             return
         todo, cur = [], 0
         for a, b in sorted(self._reduced):

@@ -160,3 +160,52 @@ def test_gradient_accumulation_matches_full_batch():
         grads.append(opt.flat_g.detach().clone())
     rel = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
     assert rel < 2e-2, rel
+
+
+def _rccl_worker(port, q):
+    """Single-rank RCCL group on the one GPU of the test box: the REAL `nccl` backend (RCCL) runs the optimizer's call
+    pattern -- async bucket all-reduces issued from inside backward on a communication stream, the tail reduce, the waits,
+    the packed log all-reduce -- and must leave the gradients of a world-size-1 mean untouched."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    from aim_amd.dist import broadcast_module, build_optimizer
+    from aim_amd.recognizer import Recognizer3D
+    model = _build()
+    broadcast_module(model)
+    opt = build_optimizer(model, dict(type='AdamW', lr=1e-2, weight_decay=0.05))
+    imgs, label = _data()
+    # reference gradient without collectives
+    opt.zero_grad()
+    model(imgs.cuda(), label.cuda(), return_loss=True)["loss_cls"].backward()
+    opt.all_reduce_grads()
+    ref = opt.flat_g.detach().clone()
+    assert opt.early_launches == 0
+    opt.force_collectives = True
+    diff = None
+    for it in range(3):
+        opt.zero_grad()
+        losses = model(imgs.cuda(), label.cuda(), return_loss=True)
+        losses["loss_cls"].backward()
+        opt.all_reduce_grads()
+        loss, log_vars = Recognizer3D._parse_losses(losses)
+        if it == 0:          # same parameters, same data: a 1-rank SUM must reproduce the un-reduced gradient bit for bit
+            diff = float((opt.flat_g.detach() - ref).abs().max())
+        opt.step()
+    torch.cuda.synchronize()
+    q.put((opt.early_launches, diff, float(log_vars["loss_cls"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_call_pattern_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    early, diff, loss = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert early == 6 and loss == loss        # two early buckets per step x 3 steps, through RCCL
+    assert diff == 0.0
