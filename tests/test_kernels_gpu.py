@@ -181,7 +181,8 @@ def _attn_ref(qkv, BT, N, H):
     return o, torch.logsumexp(s, dim=-1)
 
 
-@pytest.mark.parametrize("BT,N,H", [(2, 5, 2), (3, 50, 1), (4, 197, 12), (2, 257, 4), (1, 16, 1)])
+@pytest.mark.parametrize("BT,N,H", [(2, 5, 2), (3, 50, 1), (4, 197, 12), (2, 257, 4), (1, 16, 1),
+                                    (2, 64, 2), (2, 100, 3), (1, 224, 2), (3, 196, 2), (2, 65, 1)])   # 64 <= N <= 224: the fused backward
 def test_attn_fwd_bwd(BT, N, H):
     ops = _ops()
     D = H * 64
@@ -201,6 +202,39 @@ def test_attn_fwd_bwd(BT, N, H):
     g = x.grad
     scale = g.abs().max().item()
     close(dqkv, g, 2e-2 * scale, 3e-2, "attn dqkv")
+
+
+@pytest.mark.parametrize("BT,N,H", [(3, 197, 12), (2, 64, 1), (2, 224, 2), (5, 130, 3)])
+def test_attn_bwd_fused_matches_two_kernel_form(BT, N, H, monkeypatch):
+    """The optional fused backward (AIM_ATTN_BWD_FUSED=1: one pass, 5 products, dS exchanged through LDS) against plain
+    PyTorch autograd, like the default two-kernel form.  The switch is read once per process, so the fused kernel is
+    driven through a second copy of the library loaded with the switch set."""
+    import ctypes, shutil, tempfile, os
+    from aim_amd import lib as L
+    ops = _ops()
+    D = H * 64
+    qkv = rnd((BT * N, 3 * D), 50, 1.0, torch.bfloat16)
+    out = torch.empty((BT * N, D), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((BT, H, N), device=DEV)
+    ops.attn_fwd(qkv, out, lse, BT, N, H)
+    do = rnd((BT * N, D), 51, 1.0, torch.bfloat16)
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(x, BT, N, H)
+    ref.backward(do.float())
+    tmp = os.path.join(tempfile.mkdtemp(), "libaim_fused.so")
+    shutil.copy(L.library_path(), tmp)
+    monkeypatch.setenv("AIM_ATTN_BWD_FUSED", "1")
+    lib2 = ctypes.CDLL(tmp)
+    dq = torch.full((BT * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.zeros((BT, H, N), device=DEV)
+    lib2.aim_attn_bwd.argtypes = L.SIGNATURES["aim_attn_bwd"]
+    rc = lib2.aim_attn_bwd(qkv.data_ptr(), out.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), BT, N, H,
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    g = x.grad
+    close(dq, g, 2e-2 * g.abs().max().item(), 3e-2, "fused attn dqkv")
+    assert float(delta.abs().max()) == 0.0          # the fused kernel computes delta in LDS: the scratch stays untouched
 
 
 def test_attn_large_logits():

@@ -17,3 +17,11 @@ def t(fn, n=5):
 f = 4.0 * N * N * 64 * BT * H
 ms = t(lambda: ops.attn_fwd(qkv, out, lse, BT, N, H)); print(f"attn_fwd {ms:.3f} ms  {f/ms/1e9:.1f} TFLOP/s")
 ms = t(lambda: ops.attn_bwd(qkv, out, do, lse, delta, dqkv, BT, N, H)); print(f"attn_bwd {ms:.3f} ms  {2.5*f/ms/1e9:.1f} TFLOP/s (5 products)")
+if os.environ.get("STAMPS"):     # diagnostic build (AIM_HIP_LIB=libaim_stamps.so): per-workgroup 100 MHz time stamps in `delta`
+    delta.zero_(); torch.cuda.synchronize()
+    ops.attn_bwd(qkv, out, do, lse, delta, dqkv, BT, N, H); torch.cuda.synchronize()
+    st = delta.reshape(-1)[:7 * 2 * 6 * 2].view(torch.int64).reshape(-1, 2, 6).cpu()
+    names = ["prologue issue", "prologue wait+barrier", "first block", "remaining blocks", "epilogue"]
+    for w, nm in ((0, "producer wave 0"), (1, "consumer wave 7")):
+        d = (st[:, w, 1:] - st[:, w, :-1]).float().median(0).values * 0.01
+        print(nm, " | ".join(f"{n} {float(x):.2f} us" for n, x in zip(names, d)), "| total", float((st[:, w, 5] - st[:, w, 0]).float().median()) * 0.01)
