@@ -109,8 +109,7 @@ def aim_block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B,
     del dxl2
     # ---- x1 = x + t_hs W2^T + dp1[tok] b2,  t_hs = dp1[tok] GELU(ta W1^T + b1),  ta = attention_T(ln_1(x)) Wo^T + bo
     t_hs, t_pre, ta, dp1 = c["t_hs"], c["t_pre"], c["ta"], c["dp1"]
-    later.append(lambda: ops.colsum(dx1b, gT["D_fc2.bias"], at=dp1, ntok=N))
-    later.append(lambda: ops.wgrad(dx1b, t_hs, gT["D_fc2.weight"]))
+    later.append(lambda: ops.wgrad(dx1b, t_hs, gT["D_fc2.weight"], gT["D_fc2.bias"], at=dp1, ntok=N))
     dth_pre = _empty((M, r), BF16, dev)
     ops.gemm(dx1b, tad.W2T, ops.EPI_DACT, dth_pre, aux=t_pre, act=ops.ACT_GELU, at=dp1, ntok=N)
     later.append(lambda: ops.wgrad(dth_pre, ta, gT["D_fc1.weight"], gT["D_fc1.bias"]))

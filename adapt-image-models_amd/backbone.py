@@ -587,12 +587,11 @@ def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: 
     M, D = dyb.shape
     r, H4 = fz.r, 4 * D
     big_later: list = []
+    # D_fc2: weight gradient + the DropPath-scaled bias gradient in one pass over dyb
     if _DETACH_BIG:
-        big_later.append(lambda: ops.colsum(dyb, gm["D_fc2.bias"], at=dms2, ntok=N))
-        big_later.append(lambda: ops.wgrad(dyb, a_s, gm["D_fc2.weight"]))
+        big_later.append(lambda: ops.wgrad(dyb, a_s, gm["D_fc2.weight"], gm["D_fc2.bias"], at=dms2, ntok=N))
     else:
-        ops.colsum(dyb, gm["D_fc2.bias"], at=dms2, ntok=N)
-        ops.wgrad(dyb, a_s, gm["D_fc2.weight"])
+        ops.wgrad(dyb, a_s, gm["D_fc2.weight"], gm["D_fc2.bias"], at=dms2, ntok=N)
     dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
     ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=hcat_pre, act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
              at=dms2, ntok=N)

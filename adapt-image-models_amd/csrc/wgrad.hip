@@ -26,11 +26,19 @@ constexpr int TILE = 256;                 // output tile 256 (n) x 256 (k)
 // The kernel is bound by the bytes a CU can pull per cycle (every output tile re-reads its M-chunk of G and
 // A), so the tile is as large as the accumulators allow: [768 x 192] needs 3 tiles, 271 MB of operand reads
 // for M = 100 864 instead of 620 MB with 128 x 128 tiles.
+//
+// Bias gradient in the same pass (db != nullptr): db[n] += sum_m rs(m) G[m][n], rs(m) = at[m % ntok] (1 without `at`).  The
+// workgroups of the first k-tile column (tk == 0) already hold every G row of their chunk in LDS: thread t sums column
+// t & 255 over rows 16 (t >> 8) .. +15 of each stage beside the MFMAs (the kernel is bound by the CU's load path, not by LDS
+// or VALU issue); the per-chunk column sums go to their own slab and are added up, in chunk order, by the finish kernel.
+// This replaces a separate column-sum launch that re-read all of G from HBM (155 MB for the MLP_Adapter's D_fc2 bias).
 __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A,
                                                     int lda, float* __restrict__ dW, int lddw, float* __restrict__ partial,
-                                                    int M, int Nw, int Kw, int chunk) {
+                                                    int M, int Nw, int Kw, int chunk, float* __restrict__ db,
+                                                    float* __restrict__ bias_partial, const float* __restrict__ at, int ntok) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* smem = (AIM_LDS char*)smem_raw;
+    AIM_LDS float* sAt = (AIM_LDS float*)(smem + NST * STAGE_BYTES);     // [ntok] row factors (only with `at`)
     const int tiles_k = (Kw + TILE - 1) / TILE;
     const int tiles = ((Nw + TILE - 1) / TILE) * tiles_k;
     const int cidx = blockIdx.x / tiles, tix = blockIdx.x - cidx * tiles;
@@ -96,6 +104,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
     // stage ms (stages ms+1, ms+2 stay in flight), one barrier, re-stage buffer (ms+3)%4 -- read in
     // iteration ms-1, which every wave finished before this barrier -- then 24 tr-reads + 32 MFMA.
     const int nsteps = (rows + MSTEP - 1) / MSTEP;
+    const bool do_bias = db != nullptr && tk == 0;      // workgroup-uniform
+    float bsum = 0.f;
+    const int bcol = tid & 255, bhalf = tid >> 8;
+    if (do_bias && at) {
+        for (int i = tid; i < ntok; i += 512) sAt[i] = at[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // written before the loop's first barrier publishes it
+    }
     stage(0, 0); stage(1, 1); stage(2, 2);            // stages past the chunk are zero-fill, still counted
     for (int ms = 0; ms < nsteps; ++ms) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -103,6 +118,22 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
         stage((ms + 3) % NST, ms + 3);
         const AIM_LDS char* sG = smem + (ms % NST) * STAGE_BYTES;
         const AIM_LDS char* sA = sG + OPER_BYTES;
+        if (do_bias) {
+            // column bcol of the [32 m][256 n] stage: image bcol >> 6, 16-byte chunk (bcol & 63) >> 3 of each row
+            const AIM_LDS char* img = sG + (bcol >> 6) * IMG + (bcol & 7) * 2;
+            const int chn = (bcol & 63) >> 3;
+            int tok = at ? (mbeg + ms * MSTEP + bhalf * 16) % ntok : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (float)*(const AIM_LDS bf16_t*)(img + swz_off(bhalf * 16 + r, chn));
+                float f = 1.0f;
+                if (at) {
+                    f = sAt[tok];
+                    tok = tok + 1 == ntok ? 0 : tok + 1;
+                }
+                bsum += f * v;           // rows past the chunk are zero-filled
+            }
+        }
         bf16x8 gf[8], af[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[j] = frag(sA, wk * 64 + j * 16);
@@ -115,6 +146,17 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (do_bias) {          // the two row halves of a column meet in LDS (the stage images are dead now)
+        __syncthreads();
+        AIM_LDS float* red = (AIM_LDS float*)smem;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 256 && n0 + tid < Nw) {
+            const float v = red[tid] + red[tid + 256];
+            if (bias_partial) bias_partial[(long long)cidx * Nw + n0 + tid] = v;
+            else db[n0 + tid] += v;                    // one chunk: this workgroup is the column's only writer
+        }
+    }
     // D[i = n][j = k]: lane holds k = .. + (lane&15), n = .. + 4*(lane>>4) + e.
     // With a scratch slab the chunk's partial tile is stored plainly (slab [chunk][Nw][Kw], summed by
     // wgrad_finish_kernel: no atomics, bitwise reproducible); otherwise fp32 atomics into dW.
@@ -135,16 +177,38 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
         }
 }
 
-// dW[n][k] += sum_c slab[c][n][k]
+// dW[n][k] += sum_c slab[c][n][k]  and  db[n] += sum_c bias_slab[c][n], both in chunk order (bitwise reproducible).
+// A thread owns four consecutive outputs and walks the chunks with eight independent 16-byte loads in flight (the first
+// version issued one dependent 4-byte load per chunk: latency-bound at 80 us for 50 MB).
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                           int lddw, int nchunks, int Nw, int Kw) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                           int lddw, int nchunks, int Nw, int Kw,
+                                                           const float* __restrict__ bias_partial, float* __restrict__ db) {
     const long long total = (long long)Nw * Kw;
-    if (idx >= total) return;
-    float acc = 0.f;
-    for (int c = 0; c < nchunks; ++c) acc += partial[(long long)c * total + idx];
-    const int n = (int)(idx / Kw), k = (int)(idx - (long long)n * Kw);
-    dW[(long long)n * lddw + k] += acc;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx < total) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        for (; c + 8 <= nchunks; c += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(partial + (long long)(c + j) * total + idx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; c < nchunks; ++c) acc += *(const f32x4*)(partial + (long long)c * total + idx);
+        const int n = (int)(idx / Kw), k = (int)(idx - (long long)n * Kw);      // Kw % 8 == 0: the four outputs share a row
+        f32x4* o = (f32x4*)(dW + (long long)n * lddw + k);
+        *o = *o + acc;
+    }
+    if (bias_partial) {          // a wave per bias column, four columns per block: chunk-strided loads, fixed-order wave sum
+        const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (n < Nw) {
+            float a = 0.f;
+            for (int c = lane; c < nchunks; c += 64) a += bias_partial[(long long)c * Nw + n];
+            a = wave_sum(a);
+            if (lane == 0) db[n] += a;
+        }
+    }
 }
 
 }  // namespace
@@ -165,33 +229,48 @@ static int wgrad_chunks(int M, int tiles, int* chunk_out) {
 extern "C" int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw) {
     const int tiles = ((Nw + TILE - 1) / TILE) * ((Kw + TILE - 1) / TILE);
     const int nchunks = wgrad_chunks(M, tiles, nullptr);
-    return nchunks > 1 ? (int64_t)nchunks * Nw * Kw * 4 : 0;
+    return nchunks > 1 ? (int64_t)nchunks * Nw * (Kw + 1) * 4 : 0;      // weight slabs + one bias row per chunk
+}
+
+extern "C" int aim_wgrad_bias_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw, float* db,
+                                   const float* at, int ntok, int M, int Nw, int Kw, float* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+    AIM_CHECK_ARG(M > 0 && Nw > 0 && Kw > 0 && (Nw % 8) == 0 && (Kw % 8) == 0, "wgrad: Nw/Kw must be positive multiples of 8 (Nw=%d Kw=%d)", Nw, Kw);
+    AIM_CHECK_ARG((ldg % 8) == 0 && (lda % 8) == 0 && (lddw % 4) == 0, "wgrad: ldg/lda must be multiples of 8, lddw of 4");
+    AIM_CHECK_ARG(G && A && dW, "wgrad: null pointer");
+    AIM_CHECK_ARG(!at || (db && ntok > 0 && ntok <= 4096), "wgrad: row factors need db and 0 < ntok <= 4096");
+    const int tiles = ((Nw + TILE - 1) / TILE) * ((Kw + TILE - 1) / TILE);
+    int chunk = 0;
+    const int nchunks = wgrad_chunks(M, tiles, &chunk);
+    const int lds_bytes = NST * STAGE_BYTES + (at ? ((ntok * 4 + 15) & ~15) : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    AIM_CHECK_ARG((long long)chunk * (ldg > lda ? ldg : lda) * 2 < 0x7fffffffLL, "wgrad: chunk too large");
+    float* slab = (workspace && nchunks > 1 && workspace_bytes >= (int64_t)nchunks * Nw * (Kw + 1) * 4) ? workspace : nullptr;
+    float* bias_slab = (slab && db) ? slab + (long long)nchunks * Nw * Kw : nullptr;
+    if (db && nchunks > 1 && !slab) {       // no scratch: the bias through the stand-alone column sum (atomics inside)
+        const int rc = aim_colsum_bf16(G, ldg, nullptr, at, ntok, db, M, Nw, nullptr, 0, stream);
+        if (rc) return rc;
+        db = nullptr;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * nchunks), dim3(512), lds_bytes, (hipStream_t)stream,
+                       (const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, slab, M, Nw, Kw, chunk, db, bias_slab, at, ntok);
+    AIM_CHECK_LAUNCH("aim_wgrad_bf16");
+    if (slab) {
+        const long long total = (long long)Nw * Kw;
+        unsigned fgrid = (unsigned)((total / 4 + 255) / 256);
+        if (bias_slab && (unsigned)((Nw + 3) / 4) > fgrid) fgrid = (unsigned)((Nw + 3) / 4);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, (hipStream_t)stream,
+                           slab, dW, lddw, nchunks, Nw, Kw, bias_slab, db);
+        AIM_CHECK_LAUNCH("aim_wgrad_bf16(finish)");
+    }
+    return 0;
 }
 
 extern "C" int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw, float* db,
                               int M, int Nw, int Kw, float* workspace, int64_t workspace_bytes, void* stream) {
-    AIM_CHECK_ARG(M > 0 && Nw > 0 && Kw > 0 && (Nw % 8) == 0 && (Kw % 8) == 0, "wgrad: Nw/Kw must be positive multiples of 8 (Nw=%d Kw=%d)", Nw, Kw);
-    AIM_CHECK_ARG((ldg % 8) == 0 && (lda % 8) == 0, "wgrad: ldg/lda must be multiples of 8");
-    AIM_CHECK_ARG(G && A && dW, "wgrad: null pointer");
-    const int tiles = ((Nw + TILE - 1) / TILE) * ((Kw + TILE - 1) / TILE);
-    int chunk = 0;
-    const int nchunks = wgrad_chunks(M, tiles, &chunk);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
-        attr_set = true;
-    }
-    AIM_CHECK_ARG((long long)chunk * (ldg > lda ? ldg : lda) * 2 < 0x7fffffffLL, "wgrad: chunk too large");
-    float* slab = (workspace && nchunks > 1 && workspace_bytes >= (int64_t)nchunks * Nw * Kw * 4) ? workspace : nullptr;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * nchunks), dim3(512), NST * STAGE_BYTES, (hipStream_t)stream,
-                       (const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, slab, M, Nw, Kw, chunk);
-    AIM_CHECK_LAUNCH("aim_wgrad_bf16");
-    if (slab) {
-        const long long total = (long long)Nw * Kw;
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           slab, dW, lddw, nchunks, Nw, Kw);
-        AIM_CHECK_LAUNCH("aim_wgrad_bf16(finish)");
-    }
-    if (db) return aim_colsum_bf16(G, ldg, nullptr, nullptr, 0, db, M, Nw, nullptr, 0, stream);
-    return 0;
+    return aim_wgrad_bias_bf16(G, ldg, A, lda, dW, lddw, db, nullptr, 0, M, Nw, Kw, workspace, workspace_bytes, stream);
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "aim_gemm_expsum_tiles": [I, I],
     "aim_wgrad_bf16": [P, I, P, I, P, I, P, I, I, I, P, L, P],
     "aim_wgrad_workspace_bytes": [I, I, I],
+    "aim_wgrad_bias_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, P, L, P],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
     "aim_layernorm_fwd_fp8": [P, L, P, P, P, L, I, I, F, P],
     "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, I, P, P, L, P, P, I, I, P],

@@ -192,17 +192,16 @@ def expsum_tiles(M: int, N: int) -> int:
     return load_library().aim_gemm_expsum_tiles(M, N)
 
 
-def wgrad(g: torch.Tensor, a: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None):
-    """``dw[n,k] += sum_m g[m,n] a[m,k]``; ``db[n] += sum_m g[m,n]`` (fp32 accumulate in place)."""
-    _chk(g, BF16, "g"); _chk(a, BF16, "a"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
+def wgrad(g: torch.Tensor, a: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, at=None, ntok: int = 0):
+    """``dw[n,k] += sum_m g[m,n] a[m,k]``; ``db[n] += sum_m at[m % ntok] g[m,n]`` (``at`` None: 1) in the same pass
+    (fp32 accumulate in place; split-M partial slabs summed in a fixed order: no atomics)."""
+    _chk(g, BF16, "g"); _chk(a, BF16, "a"); _chk(dw, F32, "dw"); _chk(db, F32, "db"); _chk(at, F32, "at")
     assert g.shape[0] == a.shape[0] and dw.shape == (g.shape[1], a.shape[1])
     lib = load_library()
     nbytes = lib.aim_wgrad_workspace_bytes(g.shape[0], g.shape[1], a.shape[1])
     ws = torch.empty(nbytes // 4, dtype=F32, device=g.device) if nbytes else None
-    check(lib.aim_wgrad_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(), dw.stride(0), None,
-                             g.shape[0], g.shape[1], a.shape[1], _p(ws), nbytes, _stream()), "aim_wgrad_bf16")
-    if db is not None:
-        colsum(g, db)        # bias gradient through the two-stage (scratch) column sum
+    check(lib.aim_wgrad_bias_bf16(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(), dw.stride(0), _p(db),
+                                  _p(at), ntok, g.shape[0], g.shape[1], a.shape[1], _p(ws), nbytes, _stream()), "aim_wgrad_bias_bf16")
 
 
 def layernorm_fwd(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, ldy=None, mean=None, rstd=None,

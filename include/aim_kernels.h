@@ -127,6 +127,11 @@ int aim_wgrad_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float
                    float* workspace /* optional: aim_wgrad_workspace_bytes(); NULL -> fp32 atomics (not reproducible) */,
                    int64_t workspace_bytes, void* stream);
 int64_t aim_wgrad_workspace_bytes(int M, int Nw, int Kw);
+/* the same with the bias gradient's row factor: db[n] += sum_m at[m % ntok] * G[m][n] (at == NULL: 1), summed inside the
+ * weight-gradient kernel from the G rows it already holds in LDS (no separate pass over G).  The DropPath-scaled bias of
+ * the MLP_Adapter's D_fc2 (vit_clip.py:286) is the user. */
+int aim_wgrad_bias_bf16(const aim_bf16* G, int ldg, const aim_bf16* A, int lda, float* dW, int lddw, float* db,
+                        const float* at, int ntok, int M, int Nw, int Kw, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (fp32 statistics, eps inside rsqrt) -- vit_clip.py:71-77 (ln_1, ln_2, ln_pre, ln_post)

@@ -327,6 +327,20 @@ def test_wgrad(M, Nw, Kw):
     tol = 2e-5 * math.sqrt(M) * 4
     close(dw, ref, tol + 1e-4, 1e-4, "wgrad dW")
     close(db, db0 + g.float().sum(0), tol + 1e-4, 1e-4, "wgrad db")
+    # bias gradient with a per-token row factor (DropPath-scaled D_fc2 bias, vit_clip.py:286), G and A row-strided views
+    ntok = 197 if M > 400 else 5
+    at = (torch.rand(ntok, generator=torch.Generator().manual_seed(54)) < 0.7).float().to(DEV) / 0.7
+    wide_g = rnd((M, Nw + 64), 55, 1.0, torch.bfloat16)
+    gv = wide_g[:, 32:32 + Nw]
+    dw2, db2 = dw0.clone(), db0.clone()
+    ops.wgrad(gv, a, dw2, db2, at=at, ntok=ntok)
+    rs = at[torch.arange(M, device=DEV) % ntok]
+    close(dw2, dw0 + gv.float().T @ a.float(), tol + 1e-4, 1e-4, "wgrad dW (strided G)")
+    close(db2, db0 + (gv.float() * rs[:, None]).sum(0), tol + 1e-4, 1e-4, "wgrad db with row factors")
+    # bitwise reproducible
+    dw3, db3 = dw0.clone(), db0.clone()
+    ops.wgrad(gv, a, dw3, db3, at=at, ntok=ntok)
+    assert torch.equal(dw2, dw3) and torch.equal(db2, db3)
 
 
 # ------------------------------------------------------------------ embed / misc ---------------
