@@ -211,6 +211,18 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     }
 }
 
+// (A/B reference, AIM_WGRAD_FINISH_V=0) one output per thread, one dependent load per chunk
+__global__ __launch_bounds__(256) void wgrad_finish1_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                            int lddw, int nchunks, int Nw, int Kw) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)Nw * Kw;
+    if (idx >= total) return;
+    float acc = 0.f;
+    for (int c = 0; c < nchunks; ++c) acc += partial[(long long)c * total + idx];
+    const int n = (int)(idx / Kw), k = (int)(idx - (long long)n * Kw);
+    dW[(long long)n * lddw + k] += acc;
+}
+
 }  // namespace
 
 static int wgrad_chunks(int M, int tiles, int* chunk_out) {
@@ -250,8 +262,10 @@ extern "C" int aim_wgrad_bias_bf16(const aim_bf16* G, int ldg, const aim_bf16* A
     }
     AIM_CHECK_ARG((long long)chunk * (ldg > lda ? ldg : lda) * 2 < 0x7fffffffLL, "wgrad: chunk too large");
     float* slab = (workspace && nchunks > 1 && workspace_bytes >= (int64_t)nchunks * Nw * (Kw + 1) * 4) ? workspace : nullptr;
-    float* bias_slab = (slab && db) ? slab + (long long)nchunks * Nw * Kw : nullptr;
-    if (db && nchunks > 1 && !slab) {       // no scratch: the bias through the stand-alone column sum (atomics inside)
+    static const bool fuse_bias = [] { const char* e = getenv("AIM_WGRAD_FUSE_BIAS"); return !e || atoi(e) != 0; }();
+    static const bool finish_v = [] { const char* e = getenv("AIM_WGRAD_FINISH_V"); return !e || atoi(e) != 0; }();
+    float* bias_slab = (slab && db && fuse_bias) ? slab + (long long)nchunks * Nw * Kw : nullptr;
+    if (db && nchunks > 1 && !bias_slab) {       // no scratch: the bias through the stand-alone column sum (atomics inside)
         const int rc = aim_colsum_bf16(G, ldg, nullptr, at, ntok, db, M, Nw, nullptr, 0, stream);
         if (rc) return rc;
         db = nullptr;
@@ -263,8 +277,12 @@ extern "C" int aim_wgrad_bias_bf16(const aim_bf16* G, int ldg, const aim_bf16* A
         const long long total = (long long)Nw * Kw;
         unsigned fgrid = (unsigned)((total / 4 + 255) / 256);
         if (bias_slab && (unsigned)((Nw + 3) / 4) > fgrid) fgrid = (unsigned)((Nw + 3) / 4);
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, (hipStream_t)stream,
-                           slab, dW, lddw, nchunks, Nw, Kw, bias_slab, db);
+        if (finish_v || bias_slab)
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, (hipStream_t)stream,
+                               slab, dW, lddw, nchunks, Nw, Kw, bias_slab, db);
+        else
+            hipLaunchKernelGGL(wgrad_finish1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               slab, dW, lddw, nchunks, Nw, Kw);
         AIM_CHECK_LAUNCH("aim_wgrad_bf16(finish)");
     }
     return 0;
