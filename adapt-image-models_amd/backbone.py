@@ -569,7 +569,10 @@ def _mlp_adapter_forward(x1, fz: _Frozen, dms2, N, save: bool):
     xn = _empty((M, D), BF16, dev)
     mean2, rstd2 = _empty((M,), F32, dev), _empty((M,), F32, dev)
     ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
-    hcat_pre, hcat = _empty((M, H4 + r), BF16, dev), _empty((M, H4 + r), BF16, dev)
+    # the pre-activation is only needed by a backward: a no-grad forward passes no `out2` (the epilogue's stores to an empty
+    # buffer resource are dropped: 658 MB per ViT-B block less to write)
+    hcat_pre = _empty((M, H4 + r), BF16, dev) if (save or M < 1024) else None     # (the small-M kernel always stores it)
+    hcat = _empty((M, H4 + r), BF16, dev)
     ops.gemm(xn, fz.Wcat1, ops.EPI_ACT, hcat, bias=fz.bcat1, out2=hcat_pre, act=ops.ACT_QGELU, n_split=H4,
              act2=ops.ACT_GELU, at=dms2, ntok=N)
     x2 = _empty((M, D), F32, dev)

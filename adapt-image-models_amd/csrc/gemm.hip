@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
+    // EXPSUM problems of N = 257 tokens (ViT-L/14) are cut into 3 x 3 tiles of which five hold ONE valid row or column:
+    // a wave multiplies only the 16-row / 16-column MFMA tiles that contain a valid element (wave-uniform limits)
+    const int ilim = EPI == EPI_EXPSUM ? min(4, (rowsA - wm * 64 + 15) >> 4) : 4;
+    const int jlim = EPI == EPI_EXPSUM ? min(4, (rowsW - wn * 64 + 15) >> 4) : 4;
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -96,8 +100,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (EPI == EPI_EXPSUM) {
+                        if (i < ilim && j < jlim)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                }
         }
     }
 

@@ -116,9 +116,10 @@ def test_gemm_f32_residual_forms(frames):
     close(out, ref2, 1e-4, 1e-4, "f32 accumulate in place")
 
 
-def test_gemm_expsum_batched():
+@pytest.mark.parametrize("N", [197, 257, 129, 64, 300])       # 257 / 129 / 300: tiles holding one valid row or column
+def test_gemm_expsum_batched(N):
     ops = _ops()
-    BT, N, D = 3, 197, 256
+    BT, D = 3, 256
     qkv = rnd((BT * N, 3 * D), 21, 0.5, torch.bfloat16)
     nt = ops.expsum_tiles(N, N)
     part = torch.zeros((BT, nt, 2), device=DEV)
