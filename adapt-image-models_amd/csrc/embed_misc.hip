@@ -214,24 +214,32 @@ __global__ __launch_bounds__(256) void embed_bwd_finish_kernel(const float* __re
     dtemporal[(long long)t * D + c] += a;
 }
 
+// out[frame][d] = sum_tok w[tok] x[frame][tok][d].  Block (frame, 64-column group): 4 token groups x 64 float4-columns; a
+// thread walks tokens g, g+4, ... with eight loads in flight, the four partial sums meet in LDS in a fixed order.  (The first
+// version walked all tokens of a column in one thread, four loads in flight: latency-bound at 0.6 TB/s, and it opens the
+// backward's class-token chain.)
 template <typename TX>
 __global__ __launch_bounds__(256) void frame_sum_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ out, int ntok, int D) {
-    const int d4 = blockIdx.y * 256 + threadIdx.x;          // float4 column
-    if (d4 * 4 >= D) return;
+    __shared__ f32x4 part[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int d4 = blockIdx.y * 64 + cl;                   // float4 column
+    const bool live = d4 * 4 < D;
     const long long f = blockIdx.x;
-    const TX* p = x + f * ntok * (long long)D + d4 * 4;
+    const TX* p = x + f * ntok * (long long)D + (live ? d4 * 4 : 0);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    int t = 0;
-    for (; t + 3 < ntok; t += 4) {
-        f32x4 v[4];
+    int t = g;
+    for (; t + 28 < ntok; t += 32) {
+        f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = load4f(p + (long long)(t + u) * D);
+        for (int u = 0; u < 8; ++u) v[u] = load4f(p + (long long)(t + 4 * u) * D);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += (w ? w[t + u] : 1.0f) * v[u];
+        for (int u = 0; u < 8; ++u) acc += (w ? w[t + 4 * u] : 1.0f) * v[u];
     }
-    for (; t < ntok; ++t) acc += (w ? w[t] : 1.0f) * load4f(p + (long long)t * D);
-    *(f32x4*)(out + f * D + d4 * 4) = acc;
+    for (; t < ntok; t += 4) acc += (w ? w[t] : 1.0f) * load4f(p + (long long)t * D);
+    part[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && live) *(f32x4*)(out + f * D + d4 * 4) = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ af,
@@ -523,10 +531,10 @@ extern "C" int64_t aim_embed_bwd_workspace_bytes(int B, int T, int N, int D) {
 extern "C" int aim_frame_sum(const void* x, int x_is_bf16, const float* w, float* out, int frames, int ntok, int D, void* stream) {
     AIM_CHECK_ARG(frames > 0 && ntok > 0 && D > 0 && (D % 4) == 0 && x && out, "frame_sum: bad arguments");
     if (x_is_bf16)
-        hipLaunchKernelGGL(frame_sum_kernel<bf16_t>, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(frame_sum_kernel<bf16_t>, dim3(frames, (D / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, w, out, ntok, D);
     else
-        hipLaunchKernelGGL(frame_sum_kernel<float>, dim3(frames, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(frame_sum_kernel<float>, dim3(frames, (D / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, w, out, ntok, D);
     AIM_CHECK_LAUNCH("aim_frame_sum");
     return 0;

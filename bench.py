@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the ViT-L/14 16-frame block (BASELINE configs[3] shape)")
     ap.add_argument("--no-inference", action="store_true", help="skip the fp8 multi-view inference block (BASELINE configs[4] shape)")
     ap.add_argument("--inference-only", action="store_true", help="profiling aid: run only the inference block and print it")
+    ap.add_argument("--secondary-only", action="store_true", help="profiling aid: run only the ViT-L/14 training block and print it")
     return ap.parse_args()
 
 
@@ -242,6 +243,9 @@ def main():
 
     if args.inference_only:
         print(json.dumps(inference_l14(dev, rank, world)), flush=True)
+        return
+    if args.secondary_only:
+        print(json.dumps(secondary_l14(dev, rank, world)), flush=True)
         return
     model = build_model(args.frames, dev)
     broadcast_module(model)

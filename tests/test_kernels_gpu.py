@@ -393,6 +393,13 @@ def test_misc_reductions_and_casts():
     out = torch.zeros((frames, D), device=DEV)
     ops.frame_sum(x, w, out, frames, ntok, D)
     close(out, (x.reshape(frames, ntok, D) * w[None, :, None]).sum(1), 1e-5, 1e-5, "frame_sum")
+    for fr, nt, d in ((3, 197, 768), (2, 257, 1024), (4, 33, 64)):       # bf16 input, token counts that are not multiples of 4 / 32
+        xb, wb = rnd((fr * nt, d), 75, 1.0, torch.bfloat16), rnd((nt,), 76)
+        ob = torch.zeros((fr, d), device=DEV)
+        ops.frame_sum(xb, wb, ob, fr, nt, d)
+        close(ob, (xb.float().reshape(fr, nt, d) * wb[None, :, None]).sum(1), 1e-4, 1e-5, "frame_sum bf16")
+        ops.frame_sum(xb, None, ob, fr, nt, d)
+        close(ob, xb.float().reshape(fr, nt, d).sum(1), 1e-4, 1e-5, "frame_sum no weights")
     X = rnd((frames * ntok, D), 72, 1.0, torch.bfloat16)
     af, at = rnd((frames,), 73), rnd((ntok,), 74)
     cs = torch.zeros(D, device=DEV)
