@@ -117,3 +117,31 @@ def test_top_k_accuracy_device_matches_numpy():
     ref = top_k_accuracy(s.numpy(), lab.numpy(), (1, 5))
     got = [float(v) for v in top_k_accuracy_device(s, lab, (1, 5))]
     assert np.allclose(ref, got)
+
+
+def test_lazy_log_vars_and_aim_registry_surface():
+    """Host logic added in round 2 (no GPU): `_parse_losses` hands back lazily materialised floats; the stock-AIM class is
+    reachable through the registry with the reference's constructor keywords (vitclip_aim.py:356-358) and refuses the
+    branches that are not built."""
+    import aim_amd
+    from aim_amd.recognizer import LazyLogVars, Recognizer3D
+    losses = dict(loss_cls=torch.tensor(2.5), top1_acc=torch.tensor(0.25), top5_acc=torch.tensor(0.75))
+    loss, lv = Recognizer3D._parse_losses(losses)
+    assert isinstance(lv, LazyLogVars) and list(lv) == ["loss_cls", "top1_acc", "top5_acc", "loss"]
+    assert float(loss) == 2.5 and lv["loss"] == 2.5 and lv.get("top1_acc") == 0.25
+    assert dict(lv.items()) == dict(loss_cls=2.5, top1_acc=0.25, top5_acc=0.75, loss=2.5)
+    m = aim_amd.build_backbone(dict(type='AIM', input_resolution=32, num_frames=2, patch_size=16, width=128, layers=2, heads=2,
+                                    drop_path_rate=0.1, num_tadapter=1, adapter_scale=0.5, pretrained=None, prompt=True,
+                                    wind_attn=False, window_size=(32, 2, 2), not_shift=True))
+    assert isinstance(m, aim_amd.AIM) and isinstance(m, aim_amd.ViT_CLIP) and m.variant == 'aim'
+    m.init_weights()
+    names = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+    ref = aim_amd.ViT_CLIP(32, 2, 16, 128, 2, 2, 0.1)
+    ref.init_weights()
+    assert names == sorted(n for n, p in ref.named_parameters() if p.requires_grad)        # same state_dict keys / freeze policy
+    with pytest.raises(NotImplementedError, match="wind_attn"):
+        aim_amd.AIM(32, 2, 16, 128, 2, 2, 0.1, wind_attn=True)
+    with pytest.raises(NotImplementedError, match="num_tadapter"):
+        aim_amd.AIM(32, 2, 16, 128, 2, 2, 0.1, num_tadapter=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 2, 32, 32))
