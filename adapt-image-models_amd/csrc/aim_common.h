@@ -119,6 +119,37 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
 
+// The same LDS-DMA issued from inline assembly, for kernels that keep a staging ring in flight ACROSS transposing reads or
+// reads of a run-time-indexed buffer (wgrad.hip, the pipelined attention backward).  Through the builtin the compiler knows
+// that an LDS write is in flight and protects every LDS read it cannot tell apart from it with `s_waitcnt vmcnt(0)`:
+// ds_read_b64_tr_b16 is an intrinsic without a memory operand, so EVERY transposing read qualifies.  That drained the whole
+// ring once per step, right after the next stage had been issued.  These kernels order their reads behind the DMA themselves
+// (counted s_waitcnt vmcnt + workgroup barrier: other waves' pieces need that anyway), so the protection buys nothing.
+// Unknown to the compiler, the DMA makes the compiler's own vmcnt waits for ORDINARY loads conservative (the counter is in
+// order): keep such loads out of the span where a DMA is in flight, or retire them with __builtin_amdgcn_s_waitcnt, which the
+// compiler's scoreboard sees.  The kernel must reach vmcnt(0) before it ends or re-uses the LDS bytes.
+// (The GEMMs keep the builtin: their reads are plain ds_read_b128 of compile-time buffers, which the compiler tells apart, and
+// the opaque asm costs them 2 % in scheduling freedom.)
+typedef __attribute__((ext_vector_type(4))) int aim_rsrc_words;      // raw buffer resource words, held in SGPRs
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is a reserved register: named in the clobber list all the same
+__device__ __forceinline__ void stage_piece_asm(aim_rsrc_words rsrc, AIM_LDS char* lds_piece, unsigned voff) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(uintptr_t)lds_piece);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// stride 0, num_records = bytes, raw buffer (bounds-checked against num_records: out-of-range lanes read 0)
+__device__ __forceinline__ aim_rsrc_words make_rsrc_words(const void* base, long long bytes) {
+    const unsigned n = bytes > 0x7fffffffLL ? 0x7fffffffu : (bytes < 0 ? 0u : (unsigned)bytes);
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    aim_rsrc_words r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)n);
+    r[3] = 0x00020000;
+    return r;
+}
+
 __device__ __forceinline__ bf16x8 lds_read8(const AIM_LDS char* p) { return *(const AIM_LDS bf16x8*)p; }
 __device__ __forceinline__ bf16x4 lds_read_tr4(const AIM_LDS char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AIM_LDS bf16x4*)p);

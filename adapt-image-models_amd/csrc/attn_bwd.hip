@@ -4,7 +4,9 @@
 // Autograd counterpart of reference vit_clip.py:139-156 (the reference relies on torch autograd
 // through bmm/softmax/bmm and keeps the [BT,H,N,N] probabilities alive for it).
 //
-// Two kernels per call, one workgroup per (frame, head) each (dq: 8 waves; dkv: 4 waves, 120 VGPRs):
+// 65 <= N <= 224 tokens (ViT-B/16): ONE persistent, software-pipelined kernel (attn_bwd_pipe_kernel, below): a single pass
+// over the operands and five MFMA products.  Other N (ViT-L/14's 257, tiny test shapes), or AIM_ATTN_BWD_PIPE=0:
+// two kernels per call, one workgroup per (frame, head) each (dq: 8 waves; dkv: 4 waves):
 //   dq : query on the MFMA lane (same orientation as the forward).  Per 16-query tile and per pair
 //        of 16-key tiles:  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta) / 8 and
 //        dQ^T += K^T dS^T with the dS^T accumulators used directly as the MFMA's second operand
@@ -19,6 +21,7 @@
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -288,137 +291,301 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused backward (N <= 224: ViT-B/16's 197 tokens): ONE pass over Q, K, V, dO per (frame, head) and the five products
-// of flash attention's backward instead of seven.  One workgroup (8 waves, one per CU) per (frame, head), waves in two
-// ROLES so that nothing waits for the dS exchange:
-//   prologue   Q, dO, K -> swizzled LDS images (LDS-DMA, zero-filled past N); delta = rowsum(dO o O) and L -> LDS.
-//   producers  (waves 0 .. nkb-1; key on the MFMA lane, as attn_bwd_dkv_kernel) wave w owns keys 32w .. 32w+31 with its K / V
-//              fragments in registers and sweeps the queries in blocks of 64:  S = Q K^T, dP = dO V^T, P = exp2(S c - L),
-//              dS = P o (dP - delta);  dV^T += dO^T P and dK^T += Q^T dS with the P / dS accumulators as second operand;
-//              dS is ALSO written, as bf16, to a [key][64 query] LDS image (8-byte writes: a lane holds 4 consecutive
-//              queries of its key), double-buffered over the query blocks;
-//   consumer   (wave 7: N <= 224 leaves it no key block) dQ^T += K^T dS^T for the PREVIOUS block's 64 queries while the
-//              producers work on the next one: dS^T fragments out of the [key][query] image by ds_read_b64_tr_b16 (query
-//              on the lane), K^T fragments by transposing reads of the K image (as attn_bwd_dq_kernel);
-//   one workgroup barrier per query block; epilogue: dK, dV of each producer's 32 keys.
-// dS crosses LDS once; nothing is reduced across waves; no atomics; HBM traffic = read qkv + out + dout, write dqkv.
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16_t* __restrict__ dqkv, int N, int H, int nkb, int stagger
+// Pipelined fused backward (65 <= N <= 224: ViT-B/16's 197 tokens): ONE pass over Q, K, V, dO, O per (frame, head) and the five
+// products of flash attention's backward instead of the two kernels' seven, by a PERSISTENT workgroup per CU (8 waves) whose
+// loads run one to two 64-query blocks ahead of the arithmetic, across (frame, head) items.  An item moves 200 KB (read q, k,
+// v, dO, O; write dq, dk, dv) for 25 MFLOP: at 1/256 of the chip's HBM rate that is ~9.4 us per item, so the kernel is worth
+// as much as its loads overlap its arithmetic.  (A one-shot fused form, one workgroup per item with whole Q / dO / K images
+// in LDS, was measured first: 0.58 ms against the two kernels' 0.54 -- its 5.6 us load-bound prologue was exposed.)  This one
+// keeps only 64-query CHUNKS of Q and dO in a 2-slot LDS ring; dS crosses LDS once as bf16, nothing is reduced across waves,
+// no atomics:
+//   tick T = (item k, query block qb), flattened over the workgroup's items.  In tick T, after every wave has waited for its
+//   own loads of the previous tick (vmcnt(0)) and the workgroup barrier,
+//     every wave   ISSUES its share of chunk T+1's LDS-DMA (one Q and one dO piece per wave); at an item's second tick also
+//                  of the next item's K image, at its last tick the next item's V row fragments (producers, into registers);
+//     wave 7       (it owns no keys) finishes delta / L of chunk T+1 from registers loaded a tick earlier (dO and O row parts
+//                  straight from global memory: the ring is not involved) and requests the ones of chunk T+2;
+//     every wave   dQ of chunk T-1: wave w owns query tile w >> 1 and the two 16-wide d tiles 2 (w & 1), 2 (w & 1) + 1 and
+//                  sums over all keys: dS^T fragments out of dS image (T-1) & 1 and K^T fragments out of the item's K image,
+//                  both by transposing reads (one consumer wave doing all sixteen tiles was the critical path: 3.7 us a tick);
+//     producers    (waves 0 .. nkb-1, 32 keys each; V fragments in registers, K fragments re-read from the item's K image)
+//                  chunk T:  S, dP, P, dS, dV^T += dO^T P, dK^T += Q^T dS, dS -> [key][64 query] image T & 1;  dK / dV of an
+//                  item are stored at the next item's first tick, so the stores have a whole tick before the next vmcnt(0).
+// The tick loop is unrolled by two so that ring slot, L/delta slot and dS image are compile-time constants (with a run-time
+// parity the compiler cannot tell the slot being filled from the slot being read and drains the LDS-DMA before every read).
+// Item positions (frame, head) advance incrementally in SGPRs: no division in the loop.
+// LDS: ring 2 x 16 KiB + K images 2 x 28 KiB + dS 2 x 28 KiB + L/delta 1 KiB = 145 KiB at N = 197.  One barrier per tick.
+constexpr int PF_SLOT = 2 * 64 * 128;            // one ring slot: Q chunk [64][128 B] + dO chunk [64][128 B]
+
+struct PfPos {                                   // a tick's item: workgroup-local index, query block, frame, head
+    int k, qb, bt, h;
+};
+
+__global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, int nkb, int items
 #ifdef AIM_X_STAMPS
-                                                             , unsigned long long* stamps
+                                                            , unsigned long long* stamps
 #endif
 ) {
-#ifdef AIM_X_STAMPS
-    unsigned long long tstamp[6];
-    tstamp[0] = __builtin_amdgcn_s_memrealtime();
-#define FST(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
+#ifdef AIM_X_STAMPS      // diagnostic build: 100 MHz stamps of ticks 8..15 of workgroup 0, waves 0 and 7 (tools/bench_attn.py STAMPS=2)
+    unsigned long long tst[8][5];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) tst[a][b] = 0;
+#define PST(b) do { if (T >= 8 && T < 16) { __builtin_amdgcn_sched_barrier(0); const unsigned long long v_ = __builtin_amdgcn_s_memrealtime(); _Pragma("unroll") for (int a_ = 0; a_ < 8; ++a_) if (a_ == T - 8) tst[a_][b] = v_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
-#define FST(i)
+#define PST(b)
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // The first workgroup of every CU starts staggered (0 .. 7 x ~2 us by blockIdx % 8): all workgroups do equal work, so
-    // without it every CU of the chip sits in its load-heavy prologue at the same time (HBM-bound, ~5.6 us) and in its
-    // load-free main loop at the same time (HBM idle); the offsets persist through the CU's chain of workgroups.
-    if (stagger > 0 && blockIdx.x < 256) {
-        const int k = (int)(blockIdx.x & 7) * stagger;
-        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 clocks ~ 0.5 us
-    }
-    const int nrow = nkb * 32;                                  // rows of every image (queries and keys padded alike)
-    AIM_LDS char* sQ = (AIM_LDS char*)smem_raw;
-    AIM_LDS char* sO = sQ + nrow * 128;
-    AIM_LDS char* sK = sO + nrow * 128;
-    AIM_LDS char* sDS = sK + nrow * 128;                        // 2 x [key][64 queries] bf16
-    AIM_LDS float* sL = (AIM_LDS float*)(sDS + 2 * nrow * 128);
-    AIM_LDS float* sD = sL + nrow;
+    const int nrow = nkb * 32;                                  // keys (and query rows) padded alike
+    AIM_LDS char* sRing = (AIM_LDS char*)smem_raw;              // 2 slots
+    AIM_LDS float* sLD = (AIM_LDS float*)(sRing + 2 * PF_SLOT); // 2 x {L[64], delta[64]}
+    AIM_LDS char* sKimg = sRing + 2 * PF_SLOT + 1024;           // 2 x [nrow][128 B]: item k in buffer k & 1
+    AIM_LDS char* sDS = sKimg + 2 * nrow * 128;                 // 2 x [key][64 queries] bf16
 
-    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
-    const bf16_t* base = qkv + (long long)bt * N * ld + h * 64;
-    const bf16_t* dob = dout + (long long)bt * N * D + h * 64;
-    const bf16_t* ob = out + (long long)bt * N * D + h * 64;
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
     const bool producer = wave < nkb;
-    const bool consumer = wave == 7;                             // (nkb <= 7)
-    bf16x8 kf[2][2], vf[2][2];
-    if (producer) {
+    const bool deltaw = wave == 7;                               // (nkb <= 7: wave 7 owns no keys)
+    const int nqb = (nrow + 63) >> 6;                            // ticks per item (>= 2: N >= 65)
+    const int nit = ((int)items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nt = nit * nqb;
+    const int gbt = (int)gridDim.x / H, gh = (int)gridDim.x - gbt * H;      // item stride of the workgroup as (frames, heads)
+
+    auto advance = [&](PfPos& p) {
+        if (++p.qb == nqb) {
+            p.qb = 0;
+            ++p.k;
+            p.bt += gbt;
+            p.h += gh;
+            if (p.h >= H) {
+                p.h -= H;
+                ++p.bt;
+            }
+        }
+    };
+    f32x4 acc[16];                     // producers: dK / dV of their 32 keys
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS-DMA of a chunk into a ring slot: one Q piece and one dO piece per wave
+    auto issue_chunk = [&](const PfPos& p, AIM_LDS char* slot) {
+        const bf16_t* base = qkv + (long long)p.bt * N * ld + p.h * 64;
+        const bf16_t* dob = dout + (long long)p.bt * N * D + p.h * 64;
+        const aim_rsrc_words rQ = make_rsrc_words(base, ((long long)(N - 1) * ld + 64) * 2);
+        const aim_rsrc_words rO = make_rsrc_words(dob, ((long long)(N - 1) * D + 64) * 2);
+        const int r = p.qb * 64 + wave * 8 + srow;
+        stage_piece_asm(rQ, slot + wave * 1024, r < N ? (unsigned)((r * ld + schunk * 8) * 2) : AIM_OOB);
+        stage_piece_asm(rO, slot + 8192 + wave * 1024, r < N ? (unsigned)((r * D + schunk * 8) * 2) : AIM_OOB);
+    };
+    // delta = rowsum(dO o O) and L of a chunk, by the wave that owns no keys (wave 7), straight from global memory: 8 lanes
+    // per query row, 8 rows per load, the operands parked in that wave's otherwise unused accumulator registers.  (With every
+    // wave loading its own share, each paid ~0.5 us per tick for three loads, the shuffles and the address arithmetic.)
+    float lreg = 0.f;
+    auto issue_delta = [&](const PfPos& p) {
+        const bf16_t* ob = out + ((long long)p.bt * N * D + p.h * 64);       // wave-uniform bases, 32-bit lane offsets
+        const bf16_t* dob = dout + ((long long)p.bt * N * D + p.h * 64);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int q = p.qb * 64 + g * 8 + srow;
+            const unsigned off = (unsigned)((q < N ? q : N - 1) * D + (lane & 7) * 8);
+            acc[g] = __builtin_bit_cast(f32x4, *(const bf16x8*)(ob + off));
+            acc[8 + g] = __builtin_bit_cast(f32x4, *(const bf16x8*)(dob + off));
+        }
+        const int ql = p.qb * 64 + lane;
+        lreg = (lse + ((long long)p.bt * H + p.h) * N)[ql < N ? ql : N - 1];
+    };
+    auto finish_delta = [&](const PfPos& p, AIM_LDS float* sl) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const bf16x8 o8 = __builtin_bit_cast(bf16x8, acc[g]), d8 = __builtin_bit_cast(bf16x8, acc[8 + g]);
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)d8[e] * (float)o8[e];
+            // sum over the row's 8 lanes with DPP (quad_perm xor 1, xor 2, then row_half_mirror: the other quad of the eight);
+            // the ds_bpermute form of __shfl_xor made this wave the tick's critical path
+            dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0xB1, 0xF, 0xF, true));
+            dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x4E, 0xF, 0xF, true));
+            dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x141, 0xF, 0xF, true));
+            if ((lane & 7) == 0) sl[64 + g * 8 + srow] = p.qb * 64 + g * 8 + srow < N ? dl : 0.f;
+        }
+        sl[lane] = p.qb * 64 + lane < N ? lreg * LOG2E : 0.f;
+    };
+    auto issue_kimg = [&](const PfPos& p) {
+        const bf16_t* base = qkv + (long long)p.bt * N * ld + p.h * 64;
+        const aim_rsrc_words rK = make_rsrc_words(base + D, ((long long)(N - 1) * ld + 64) * 2);
+        AIM_LDS char* img = sKimg + (p.k & 1) * nrow * 128;
+        for (int pc = wave; pc < nrow / 8; pc += 8) {
+            const int r = pc * 8 + srow;
+            stage_piece_asm(rK, img + pc * 1024, r < N ? (unsigned)((r * ld + schunk * 8) * 2) : AIM_OOB);
+        }
+    };
+    bf16x8 vf[2][2] = {}, vfn[2][2] = {};
+    auto issue_v = [&](const PfPos& p) {        // producers: V row fragments of an item -> vfn
+        const bf16_t* base = qkv + (long long)p.bt * N * ld + p.h * 64;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int key = wave * 32 + u * 16 + frow;
             const int kc = key < N ? key : N - 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kf[u][ks] = *(const bf16x8*)(base + (long long)kc * ld + D + (ks * 4 + fq) * 8);
-                vf[u][ks] = *(const bf16x8*)(base + (long long)kc * ld + 2 * D + (ks * 4 + fq) * 8);
-            }
+            for (int ks = 0; ks < 2; ++ks) vfn[u][ks] = *(const bf16x8*)(base + (long long)kc * ld + 2 * D + (ks * 4 + fq) * 8);
         }
-    }
-    {
-        __amdgpu_buffer_rsrc_t rQ = make_rsrc(base, ((long long)(N - 1) * ld + 64) * 2);
-        __amdgpu_buffer_rsrc_t rK = make_rsrc(base + D, ((long long)(N - 1) * ld + 64) * 2);
-        __amdgpu_buffer_rsrc_t rO = make_rsrc(dob, ((long long)(N - 1) * D + 64) * 2);
-        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-        for (int p = wave; p < nrow / 8; p += 8) {
-            const int r = p * 8 + srow;
-            const unsigned vq = r < N ? (unsigned)((r * ld + schunk * 8) * 2) : AIM_OOB;
-            stage_piece(rQ, sQ + p * 1024, vq);
-            stage_piece(rK, sK + p * 1024, vq);
-            stage_piece(rO, sO + p * 1024, r < N ? (unsigned)((r * D + schunk * 8) * 2) : AIM_OOB);
-        }
-        // delta = rowsum(dO o O): 4 lanes per query, 16 head-dim elements each.  ALL loads of the prologue are issued before
-        // anything waits (one HBM round trip for the LDS-DMA images, the dO / O rows, L and the K / V fragments below)
-        bf16x8 da[2][2], oa2[2][2];
-        float lq[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int q = it * 128 + (tid >> 2), part = tid & 3;
-            const int qc = q < N ? q : N - 1;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                da[it][c] = *(const bf16x8*)(dob + (long long)qc * D + part * 16 + c * 8);
-                oa2[it][c] = *(const bf16x8*)(ob + (long long)qc * D + part * 16 + c * 8);
-            }
-            lq[it] = lse[((long long)bt * H + h) * N + qc];
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int q = it * 128 + (tid >> 2), part = tid & 3;
-            float dl = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dl += (float)da[it][c][e] * (float)oa2[it][c][e];
-            dl += __shfl_xor(dl, 1, 64);
-            dl += __shfl_xor(dl, 2, 64);
-            if (part == 0 && q < nrow) {
-                sD[q] = q < N ? dl : 0.f;
-                sL[q] = q < N ? lq[it] * LOG2E : 0.f;
-            }
-        }
-    }
-    // producers: dK / dV of their 32 keys; consumer: dQ of one 64-query block (the same registers serve either role)
-    f32x4 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    FST(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    FST(2);
+    };
 
-    const int nqb = (nrow + 63) >> 6;
-    for (int qb = 0; qb <= nqb; ++qb) {
-        if (producer && qb < nqb) {
-            AIM_LDS char* ds_img = sDS + (qb & 1) * nrow * 128;
+    auto store_dkv = [&](const PfPos& p) {      // producers: dK, dV of an item from acc
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key = wave * 32 + u * 16 + frow;
+            bf16_t* op = dqkv + ((long long)p.bt * N + (key < N ? key : 0)) * ld + p.h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
+#pragma unroll
+            for (int dt = 0; dt < 4; dt += 2) {
+                const f32x4 k0 = acc[dt * 2 + u] * 0.125f, k1 = acc[(dt + 1) * 2 + u] * 0.125f;
+                const f32x4 v0 = acc[8 + dt * 2 + u], v1 = acc[8 + (dt + 1) * 2 + u];
+                const bf16x8 vk = pair_rows16(pack4(k0[0], k0[1], k0[2], k0[3]), pack4(k1[0], k1[1], k1[2], k1[3]));
+                const bf16x8 vv = pair_rows16(pack4(v0[0], v0[1], v0[2], v0[3]), pack4(v1[0], v1[1], v1[2], v1[3]));
+                if (key < N) {
+                    *(bf16x8*)(op + D + dt * 16) = vk;
+                    *(bf16x8*)(op + 2 * D + dt * 16) = vv;
+                }
+            }
+        }
+    };
+
+    // positions of ticks T-1, T, T+1, T+2
+    PfPos prv{0, 0, 0, 0}, cur, nx1, nx2;
+    cur.k = 0;
+    cur.qb = 0;
+    cur.bt = (int)blockIdx.x / H;
+    cur.h = (int)blockIdx.x - cur.bt * H;
+    nx1 = cur;
+    advance(nx1);
+    nx2 = nx1;
+    advance(nx2);
+
+    // ---- prologue: chunk 0 and its delta, item 0's K image and V fragments; then the delta operands of chunk 1
+    issue_chunk(cur, sRing);
+    if (deltaw) issue_delta(cur);
+    issue_kimg(cur);
+    if (producer) issue_v(cur);
+    __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0), as a builtin: see the tick's wait
+    if (deltaw) {
+        finish_delta(cur, sLD);
+        if (nt > 1) issue_delta(nx1);
+    }
+
+    // one tick; P = T & 1 as a compile-time constant
+    auto tick = [&](int T, auto PAR) {
+        constexpr int P = decltype(PAR)::value;
+        PST(0);
+        // vmcnt(0) lgkmcnt(0) as a BUILTIN so that the compiler's scoreboard sees it: behind an asm wait it still counts the
+        // register loads of the previous tick (O / dO parts, V fragments) as outstanding and waits for them with a count that
+        // ignores the LDS-DMA issued since -- i.e. for the DMA this tick has just started
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_sched_barrier(0);
+        PST(1);
+        __builtin_amdgcn_s_barrier();
+        PST(2);
+        const bool live = T < nt;
+        // item switch first: the loads these registers come from were issued a tick ago, nothing else is in flight yet
+        if (producer && live && cur.qb == 0) {
+            if (T > 0) {
+                store_dkv(prv);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) vf[u][ks] = vfn[u][ks];
+        }
+        if (producer && !live && nt > 0) store_dkv(prv);         // the last item's dK / dV (T == nt)
+        // The tick's loads
+        if (T + 1 < nt) {
+            if (deltaw) finish_delta(nx1, sLD + (1 - P) * 128);
+            issue_chunk(nx1, sRing + (1 - P) * PF_SLOT);
+        }
+        if (deltaw && T + 2 < nt) issue_delta(nx2);
+        if (live) {
+            if (cur.qb == 1 && cur.k + 1 < nit) {        // the next item's K image (nx1 / nx2 may still be inside this item)
+                PfPos nk = cur;
+                nk.qb = nqb - 1;
+                advance(nk);
+                issue_kimg(nk);
+            }
+            if (cur.qb == nqb - 1 && cur.k + 1 < nit && producer) issue_v(nx1);
+        }
+        PST(3);
+        if (T > 0) {
+            // dQ of chunk T-1 (its dS image was completed before this tick's barrier): query tile wave >> 1, d tiles dt0, dt0 + 1
+            const int qt = wave >> 1, dt0 = (wave & 1) * 2;
+            const int nqt = min(4, (N - prv.qb * 64 + 15) >> 4);          // query tiles of the chunk that hold a query < N
+            if (qt < nqt) {
+                // lane-derived LDS offsets are recomputed per section: kept as loop invariants they (and the producer
+                // section's) cost ~40 VGPRs across the tick loop and spill, and a scratch reload waits on vmcnt
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int frow = ln & 15, fq = ln >> 4;
+                const AIM_LDS char* sK = sKimg + (prv.k & 1) * nrow * 128;
+                const AIM_LDS char* ds_img = sDS + (1 - P) * nrow * 128;
+                f32x4 dq0 = f32x4{0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+                const int chq = qt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                const int chk0 = dt0 * 2 + ((frow & 3) >> 1), chk1 = chk0 + 2;
+                for (int kk = 0; kk < nkb; ++kk) {
+                    const int r0 = kk * 32 + fq * 4 + (frow >> 2);
+                    const bf16x4 sa = lds_read_tr4(ds_img + swz_off(r0, chq) + half);
+                    const bf16x4 sb = lds_read_tr4(ds_img + swz_off(r0 + 16, chq) + half);
+                    const bf16x4 ka = lds_read_tr4(sK + swz_off(r0, chk0) + half);
+                    const bf16x4 kb = lds_read_tr4(sK + swz_off(r0 + 16, chk0) + half);
+                    const bf16x4 kc = lds_read_tr4(sK + swz_off(r0, chk1) + half);
+                    const bf16x4 kd = lds_read_tr4(sK + swz_off(r0 + 16, chk1) + half);
+                    bf16x8 dsT, kt0, kt1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dsT[e] = sa[e];
+                        dsT[4 + e] = sb[e];
+                        kt0[e] = ka[e];
+                        kt0[4 + e] = kb[e];
+                        kt1[e] = kc[e];
+                        kt1[4 + e] = kd[e];
+                    }
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsT, dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsT, dq1, 0, 0, 0);
+                }
+                // lane holds dQ[q][d = 16 dt + 4 fq + e]; tiles (dt0, dt0+1) paired across even / odd 16-lane rows: 16-byte stores
+                const int q = prv.qb * 64 + qt * 16 + frow;
+                bf16_t* op = dqkv + ((long long)prv.bt * N + (q < N ? q : 0)) * ld + prv.h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
+                const f32x4 a = dq0 * 0.125f, b = dq1 * 0.125f;
+                const bf16x8 v = pair_rows16(pack4(a[0], a[1], a[2], a[3]), pack4(b[0], b[1], b[2], b[3]));
+                if (q < N) *(bf16x8*)(op + dt0 * 16) = v;
+            }
+        }
+        if (producer && live) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int frow = ln & 15, fq = ln >> 4;
+            const AIM_LDS char* sQ = sRing + P * PF_SLOT;
+            const AIM_LDS char* sO = sQ + 8192;
+            const AIM_LDS float* sL = sLD + P * 128;
+            const AIM_LDS float* sD = sL + 64;
+            const AIM_LDS char* sK = sKimg + (cur.k & 1) * nrow * 128;
+            AIM_LDS char* ds_img = sDS + P * nrow * 128;
+            bf16x8 kf[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) kf[u][ks] = lds_read8(sK + swz_off(wave * 32 + u * 16 + frow, ks * 4 + fq));
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
-                const int qs = qb * 2 + hs;                      // 32-query step
-                if (qs * 32 >= nrow) break;
+                if ((cur.qb * 2 + hs) * 32 >= nrow) break;       // the item's last 32-query step may be its chunk's first
                 bf16x4 ta[4], tb[4], tc[4], td[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const int r0 = qs * 32 + fq * 4 + (frow >> 2);
+                    const int r0 = hs * 32 + fq * 4 + (frow >> 2);
                     const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
                     ta[dt] = lds_read_tr4(sQ + swz_off(r0, ch) + half);
                     tb[dt] = lds_read_tr4(sQ + swz_off(r0 + 16, ch) + half);
@@ -428,19 +595,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
                 bf16x8 pf[2], dsf[2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
-                    const int qrow = (2 * qs + w) * 16;
+                    const int qrow = (2 * hs + w) * 16;
                     bf16x8 qa[2], oa[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         qa[ks] = lds_read8(sQ + swz_off(qrow + frow, ks * 4 + fq));
                         oa[ks] = lds_read8(sO + swz_off(qrow + frow, ks * 4 + fq));
                     }
-                    float Lr[4], Dr[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        Lr[e] = sL[qrow + fq * 4 + e];
-                        Dr[e] = sD[qrow + fq * 4 + e];
-                    }
+                    const f32x4 Lr = *(const AIM_LDS f32x4*)(sL + qrow + fq * 4);
+                    const f32x4 Dr = *(const AIM_LDS f32x4*)(sD + qrow + fq * 4);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -459,7 +622,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
                             ds4[e] = d;
                         }
                         // dS[q = qrow + 4 fq + e][key = 32 wave + 16 u + frow] -> image row = key, 4 consecutive queries
-                        const int ql = hs * 32 + w * 16 + fq * 4;                    // query inside the 64-query block
+                        const int ql = qrow + fq * 4;                                    // query inside the 64-query chunk
                         *(AIM_LDS bf16x4*)(ds_img + swz_off(wave * 32 + u * 16 + frow, ql >> 3) + (ql & 7) * 2) = ds4;
                     }
                 }
@@ -481,89 +644,23 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
                 }
             }
         }
-        if (consumer && qb > 0) {
-            // dQ of block qb-1 (its dS image was completed before the barrier that ended the previous iteration)
-            const int pb = qb - 1;
-            const AIM_LDS char* ds_img = sDS + (pb & 1) * nrow * 128;
-            const int nqt = min(4, (N - pb * 64 + 15) >> 4);              // query tiles of this block that hold a query < N
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kk = 0; kk < nkb; ++kk) {
-                const int r0 = kk * 32 + fq * 4 + (frow >> 2);
-                bf16x8 ktf[4];
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
-                    const bf16x4 a = lds_read_tr4(sK + swz_off(r0, ch) + half);
-                    const bf16x4 b = lds_read_tr4(sK + swz_off(r0 + 16, ch) + half);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ktf[dt][e] = a[e];
-                        ktf[dt][4 + e] = b[e];
-                    }
-                }
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    if (qt < nqt) {                                         // wave-uniform
-                        const int ch = qt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
-                        const bf16x4 a = lds_read_tr4(ds_img + swz_off(r0, ch) + half);
-                        const bf16x4 b = lds_read_tr4(ds_img + swz_off(r0 + 16, ch) + half);
-                        bf16x8 dsT;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            dsT[e] = a[e];
-                            dsT[4 + e] = b[e];
-                        }
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt)
-                            acc[qt * 4 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt], dsT, acc[qt * 4 + dt], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                const int q = pb * 64 + qt * 16 + frow;
-                if (qt < nqt) {
-                    // lane holds dQ[q][d = 16 dt + 4 fq + e]; tiles (dt, dt+1) paired across even / odd 16-lane rows: 16-byte stores
-                    bf16_t* op = dqkv + ((long long)bt * N + (q < N ? q : 0)) * ld + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
-#pragma unroll
-                    for (int dt = 0; dt < 4; dt += 2) {
-                        const f32x4 a = acc[qt * 4 + dt] * 0.125f, b = acc[qt * 4 + dt + 1] * 0.125f;
-                        const bf16x8 v = pair_rows16(pack4(a[0], a[1], a[2], a[3]), pack4(b[0], b[1], b[2], b[3]));
-                        if (q < N) *(bf16x8*)(op + dt * 16) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#ifdef AIM_X_STAMPS
-        if (qb == 0) FST(3);
-#endif
-    }
-    FST(4);
-    if (producer) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int key = wave * 32 + u * 16 + frow;
-            bf16_t* op = dqkv + ((long long)bt * N + (key < N ? key : 0)) * ld + h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
-#pragma unroll
-            for (int dt = 0; dt < 4; dt += 2) {
-                const f32x4 k0 = acc[dt * 2 + u] * 0.125f, k1 = acc[(dt + 1) * 2 + u] * 0.125f;
-                const f32x4 v0 = acc[8 + dt * 2 + u], v1 = acc[8 + (dt + 1) * 2 + u];
-                const bf16x8 vk = pair_rows16(pack4(k0[0], k0[1], k0[2], k0[3]), pack4(k1[0], k1[1], k1[2], k1[3]));
-                const bf16x8 vv = pair_rows16(pack4(v0[0], v0[1], v0[2], v0[3]), pack4(v1[0], v1[1], v1[2], v1[3]));
-                if (key < N) {
-                    *(bf16x8*)(op + D + dt * 16) = vk;
-                    *(bf16x8*)(op + 2 * D + dt * 16) = vv;
-                }
-            }
-        }
+        PST(4);
+        prv = cur;
+        cur = nx1;
+        nx1 = nx2;
+        advance(nx2);
+    };
+    for (int T = 0; T <= nt; T += 2) {
+        tick(T, std::integral_constant<int, 0>{});
+        if (T + 1 <= nt) tick(T + 1, std::integral_constant<int, 1>{});
     }
 #ifdef AIM_X_STAMPS
-    FST(5);
-    if (stamps && blockIdx.x % 997 == 0 && lane == 0 && (wave == 0 || wave == 7)) {
-        unsigned long long* o = stamps + ((blockIdx.x / 997) * 2 + (wave == 7)) * 6;
-        for (int i = 0; i < 6; ++i) o[i] = tstamp[i];
+    if (stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long* o = stamps + (wave == 7 ? 40 : 0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) o[a * 5 + b] = tst[a][b];
     }
 #endif
 }
@@ -576,30 +673,31 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
     AIM_CHECK_ARG(BT > 0 && N > 0 && H > 0 && N <= 288, "attn_bwd: unsupported shape BT=%d N=%d H=%d (N <= 288)", BT, N, H);
     AIM_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    // AIM_ATTN_BWD_FUSED=1 (64 <= N <= 224, ViT-B/16): the fused single-pass kernel.  Measured on MI355X (512 x 12 x 197 x 64):
-    // 0.56-0.60 ms against 0.54-0.58 ms for the two kernels stand-alone, and the same 57.85 ms whole step (the backward GEMMs
-    // beside it run 5 % faster, the attention itself slower): it moves 1/3 less HBM traffic and issues 5 products instead of
-    // 7, but runs one workgroup per CU (145 KB of LDS), so its 5.6 us load-bound prologue and its VALU-latency-bound
-    // 1.4 us per 32-query step are exposed (tools/bench_attn.py STAMPS=1).  Kept as the starting point for a persistent,
-    // software-pipelined version; the two-kernel form stays the default.
-    static const bool fused_on = [] { const char* e = getenv("AIM_ATTN_BWD_FUSED"); return e && atoi(e) != 0; }();
-    if (fused_on && N <= 224 && N >= 64) {
+    // 65 <= N <= 224 (ViT-B/16's 197 tokens): the pipelined fused kernel; AIM_ATTN_BWD_PIPE=0 selects the two-kernel form.
+    // Measured on MI355X (512 x 12 x 197 x 64, stand-alone): 0.39 ms against 0.54 ms; whole training step 53.8 against 54.7 ms.
+    static const bool pipe_on = [] { const char* e = getenv("AIM_ATTN_BWD_PIPE"); return !e || atoi(e) != 0; }();
+    if (pipe_on && N <= 224 && N >= 65) {
         const int nkb = (N + 31) / 32;
         const int nrow = nkb * 32;
-        const int lds = 5 * nrow * 128 + nrow * 8;
-        static const int stagger = [] { const char* e = getenv("AIM_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
+        const int lds = 2 * PF_SLOT + 4 * nrow * 128 + 2 * 128 * 4;
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set2 = true;
         }
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(BT * H), dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                           (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nkb, stagger
+        const int items = BT * H;
+        int cus = 256;
+        { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+        static const int grid_cap = [] { const char* e = getenv("AIM_ATTN_PIPE_GRID"); return e ? atoi(e) : 0; }();   // tests: few workgroups, many items each
+        if (grid_cap > 0 && grid_cap < cus) cus = grid_cap;
+        const int grid = items < cus ? items : cus;
+        hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(grid), dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nkb, items
 #ifdef AIM_X_STAMPS
-                           , (unsigned long long*)delta      // diagnostic build: the (unused) delta scratch receives time stamps
+                           , (unsigned long long*)delta
 #endif
         );
-        AIM_CHECK_LAUNCH("aim_attn_bwd(fused)");
+        AIM_CHECK_LAUNCH("aim_attn_bwd(pipelined)");
         return 0;
     }
     const int nkt = ((N + 31) / 32) * 2;   // 16-key tiles, even

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
     const bf16_t* Gb = G + (long long)mbeg * ldg + n0;
     const bf16_t* Ab = A + (long long)mbeg * lda + k0;
     const int rows = mend - mbeg;
-    __amdgpu_buffer_rsrc_t rG = make_rsrc(Gb, ((long long)(rows - 1) * ldg + min(TILE, Nw - n0)) * 2);
-    __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab, ((long long)(rows - 1) * lda + min(TILE, Kw - k0)) * 2);
+    aim_rsrc_words rG = make_rsrc_words(Gb, ((long long)(rows - 1) * ldg + min(TILE, Nw - n0)) * 2);
+    aim_rsrc_words rA = make_rsrc_words(Ab, ((long long)(rows - 1) * lda + min(TILE, Kw - k0)) * 2);
 
     // staging: per operand 16 pieces (4 column images x 4 row groups of 8); a wave takes 2 of each
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
             const int col = img * 64 + schunk * 8;
             const unsigned vg = (r < rows && n0 + col < Nw) ? (unsigned)((r * ldg + col) * 2) : AIM_OOB;
             const unsigned va = (r < rows && k0 + col < Kw) ? (unsigned)((r * lda + col) * 2) : AIM_OOB;
-            stage_piece(rG, dG + img * IMG + rg * 1024, vg);
-            stage_piece(rA, dA + img * IMG + rg * 1024, va);
+            stage_piece_asm(rG, dG + img * IMG + rg * 1024, vg);
+            stage_piece_asm(rA, dA + img * IMG + rg * 1024, va);
         }
     };
 

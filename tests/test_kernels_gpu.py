@@ -183,7 +183,7 @@ def _attn_ref(qkv, BT, N, H):
 
 
 @pytest.mark.parametrize("BT,N,H", [(2, 5, 2), (3, 50, 1), (4, 197, 12), (2, 257, 4), (1, 16, 1),
-                                    (2, 64, 2), (2, 100, 3), (1, 224, 2), (3, 196, 2), (2, 65, 1)])   # 64 <= N <= 224: the fused backward
+                                    (2, 64, 2), (2, 100, 3), (1, 224, 2), (3, 196, 2), (2, 65, 1)])   # 65 <= N <= 224: the pipelined fused backward
 def test_attn_fwd_bwd(BT, N, H):
     ops = _ops()
     D = H * 64
@@ -205,11 +205,11 @@ def test_attn_fwd_bwd(BT, N, H):
     close(dqkv, g, 2e-2 * scale, 3e-2, "attn dqkv")
 
 
-@pytest.mark.parametrize("BT,N,H", [(3, 197, 12), (2, 64, 1), (2, 224, 2), (5, 130, 3)])
-def test_attn_bwd_fused_matches_two_kernel_form(BT, N, H, monkeypatch):
-    """The optional fused backward (AIM_ATTN_BWD_FUSED=1: one pass, 5 products, dS exchanged through LDS) against plain
-    PyTorch autograd, like the default two-kernel form.  The switch is read once per process, so the fused kernel is
-    driven through a second copy of the library loaded with the switch set."""
+@pytest.mark.parametrize("BT,N,H", [(3, 197, 12), (2, 65, 1), (2, 224, 2), (5, 130, 3)])
+def test_attn_bwd_two_kernel_form(BT, N, H, monkeypatch):
+    """65 <= N <= 224 runs the pipelined fused backward by default; the two-kernel form (AIM_ATTN_BWD_PIPE=0: what N = 257 and
+    the tiny shapes always run) is checked at these sizes too, against plain PyTorch autograd.  The switch is read once per
+    process, so it is driven through a second copy of the library loaded with the switch set."""
     import ctypes, shutil, tempfile, os
     from aim_amd import lib as L
     ops = _ops()
@@ -222,9 +222,9 @@ def test_attn_bwd_fused_matches_two_kernel_form(BT, N, H, monkeypatch):
     x = qkv.float().requires_grad_(True)
     ref, _ = _attn_ref(x, BT, N, H)
     ref.backward(do.float())
-    tmp = os.path.join(tempfile.mkdtemp(), "libaim_fused.so")
+    tmp = os.path.join(tempfile.mkdtemp(), "libaim_two.so")
     shutil.copy(L.library_path(), tmp)
-    monkeypatch.setenv("AIM_ATTN_BWD_FUSED", "1")
+    monkeypatch.setenv("AIM_ATTN_BWD_PIPE", "0")
     lib2 = ctypes.CDLL(tmp)
     dq = torch.full((BT * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
     delta = torch.zeros((BT, H, N), device=DEV)
@@ -234,8 +234,46 @@ def test_attn_bwd_fused_matches_two_kernel_form(BT, N, H, monkeypatch):
     assert rc == 0
     torch.cuda.synchronize()
     g = x.grad
-    close(dq, g, 2e-2 * g.abs().max().item(), 3e-2, "fused attn dqkv")
-    assert float(delta.abs().max()) == 0.0          # the fused kernel computes delta in LDS: the scratch stays untouched
+    close(dq, g, 2e-2 * g.abs().max().item(), 3e-2, "two-kernel attn dqkv")
+    assert float(delta.abs().max()) > 0.0           # this form writes delta = rowsum(dO o O) to the scratch
+
+
+@pytest.mark.parametrize("BT,N,H,grid", [(3, 197, 12, 5), (2, 65, 1, 1), (2, 224, 2, 3), (5, 130, 3, 4), (4, 96, 2, 8), (30, 197, 12, 0)])
+def test_attn_bwd_pipelined(BT, N, H, grid, monkeypatch):
+    """The pipelined fused backward (the default for 65 <= N <= 224: persistent workgroups, loads one to two query blocks
+    ahead across (frame, head) items) against plain PyTorch autograd.  AIM_ATTN_PIPE_GRID caps the grid so that a workgroup
+    walks several items (item switches, K-image double buffer, deferred dK / dV stores) even at test sizes; run twice for
+    bit-equality."""
+    import ctypes, shutil, tempfile, os
+    from aim_amd import lib as L
+    ops = _ops()
+    D = H * 64
+    qkv = rnd((BT * N, 3 * D), 60, 1.0, torch.bfloat16)
+    out = torch.empty((BT * N, D), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((BT, H, N), device=DEV)
+    ops.attn_fwd(qkv, out, lse, BT, N, H)
+    do = rnd((BT * N, D), 61, 1.0, torch.bfloat16)
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(x, BT, N, H)
+    ref.backward(do.float())
+    tmp = os.path.join(tempfile.mkdtemp(), "libaim_pipe.so")
+    shutil.copy(L.library_path(), tmp)
+    if grid:
+        monkeypatch.setenv("AIM_ATTN_PIPE_GRID", str(grid))
+    lib2 = ctypes.CDLL(tmp)
+    lib2.aim_attn_bwd.argtypes = L.SIGNATURES["aim_attn_bwd"]
+    res = []
+    for _ in range(2):
+        dq = torch.full((BT * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        delta = torch.zeros((BT, H, N), device=DEV)
+        rc = lib2.aim_attn_bwd(qkv.data_ptr(), out.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), BT, N, H,
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append(dq)
+    g = x.grad
+    close(res[0], g, 2e-2 * g.abs().max().item(), 3e-2, "pipelined attn dqkv")
+    assert torch.equal(res[0], res[1])
 
 
 def test_attn_large_logits():

@@ -25,3 +25,14 @@ if os.environ.get("STAMPS"):     # diagnostic build (AIM_HIP_LIB=libaim_stamps.s
     for w, nm in ((0, "producer wave 0"), (1, "consumer wave 7")):
         d = (st[:, w, 1:] - st[:, w, :-1]).float().median(0).values * 0.01
         print(nm, " | ".join(f"{n} {float(x):.2f} us" for n, x in zip(names, d)), "| total", float((st[:, w, 5] - st[:, w, 0]).float().median()) * 0.01)
+
+if os.environ.get("STAMPS") == "2":  # pipelined kernel: ticks 8..15 of workgroup 0, waves 0 (producer) and 7 (consumer)
+    delta.zero_(); torch.cuda.synchronize()
+    ops.attn_bwd(qkv, out, do, lse, delta, dqkv, BT, N, H); torch.cuda.synchronize()
+    st = delta.reshape(-1)[:160].view(torch.int64).reshape(2, 8, 5).cpu()
+    for w, nm in ((0, "producer wave 0"), (1, "consumer wave 7")):
+        print(nm)
+        for a in range(8):
+            r = st[w, a]
+            nxt = st[w, a + 1, 0] if a < 7 else r[4]
+            print(f"  tick {8 + a}: wait {(r[1]-r[0])*0.01:.2f} barrier {(r[2]-r[1])*0.01:.2f} issue {(r[3]-r[2])*0.01:.2f} compute {(r[4]-r[3])*0.01:.2f} | tick {(nxt-r[0])*0.01:.2f} us")
