@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], gf[i], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (do_bias) {          // the two row halves of a column meet in LDS (the stage images are dead now)
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
             else db[n0 + tid] += v;                    // one chunk: this workgroup is the column's only writer
         }
     }
-    // D[i = n][j = k]: lane holds k = .. + (lane&15), n = .. + 4*(lane>>4) + e.
+    // The MFMA is issued with the A fragment FIRST (D[k][n]): the lane holds n = .. + (lane & 15) and the four consecutive
+    // k = .. + 4 * (lane >> 4) + e, so a partial tile leaves as 16-byte stores (32 per wave; the 4-byte form, 128 per wave,
+    // took 7.6 us of a 46 us workgroup).
     // With a scratch slab the chunk's partial tile is stored plainly (slab [chunk][Nw][Kw], summed by
     // wgrad_finish_kernel: no atomics, bitwise reproducible); otherwise fp32 atomics into dW.
     float* slab = partial ? partial + (long long)cidx * Nw * Kw : nullptr;
@@ -165,15 +167,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wk * 64 + j * 16 + frow;
-            if (k >= Kw) continue;
+            const int n = n0 + wn * 128 + i * 16 + frow;
+            const int k = k0 + wk * 64 + j * 16 + fq * 4;
+            if (n >= Nw || k >= Kw) continue;          // Kw is a multiple of 8: a lane's four k are in range together
+            if (slab) *(f32x4*)(slab + (long long)n * Kw + k) = acc[i][j];
+            else
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + wn * 128 + i * 16 + fq * 4 + e;
-                if (n >= Nw) continue;
-                if (slab) slab[(long long)n * Kw + k] = acc[i][j][e];
-                else atomicAdd(dW + (long long)n * lddw + k, acc[i][j][e]);
-            }
+                for (int e = 0; e < 4; ++e) atomicAdd(dW + (long long)n * lddw + k + e, acc[i][j][e]);
         }
 }
 
