@@ -229,6 +229,7 @@ _ELEM = {BF16: 2, F32: 4}
 # attention kernels, which do not depend on it; the two are joined with events before `lamda`.
 _SIDE = {}
 _DETACHED = {}
+
 _JOIN_STATS = [] if os.environ.get("AIM_JOIN_STATS") else None     # (tag, event, event) per join
 
 
@@ -243,6 +244,8 @@ def join_stats():
 _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
 _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
+_DEFER_JOIN = os.environ.get("AIM_DEFER_JOIN", "1") != "0"     # (A/B switch) join the class-token chain after ln_1 backward
+_FSUM_IN_LN = os.environ.get("AIM_FSUM_IN_LN", "1") != "0"     # (A/B switch) per-frame d(x1) sums from the ln_2 backward
 _CLS_EARLY = os.environ.get("AIM_CLS_EARLY", "1") != "0"
 _LAMBDA_FUSED = os.environ.get("AIM_LAMBDA_FUSED", "1") != "0"
 _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
@@ -304,10 +307,17 @@ class _Fork:
                         fork.sync_side_to_main()
                     self_inner.ctx = torch.cuda.stream(fork.side_stream)
                     self_inner.ctx.__enter__()
+                    if _JOIN_STATS is not None:      # diagnostics: the section's own span on the side stream
+                        self_inner.t0 = torch.cuda.Event(enable_timing=True)
+                        self_inner.t0.record(fork.side_stream)
                 return fork
 
             def __exit__(self_inner, *exc):
                 if fork.enabled:
+                    if _JOIN_STATS is not None:
+                        t1 = torch.cuda.Event(enable_timing=True)
+                        t1.record(fork.side_stream)
+                        _JOIN_STATS.append((fork.tag + "-span", self_inner.t0, t1))
                     self_inner.ctx.__exit__(*exc)
                 return False
 
@@ -583,9 +593,10 @@ def _mlp_adapter_forward(x1, fz: _Frozen, dms2, N, save: bool):
     return x2, xn, mean2, rstd2, hcat_pre, a_s
 
 
-def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: _Frozen, gm, N):
+def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: _Frozen, gm, N, fsum=None):
     """Backward of ``_mlp_adapter_forward``: returns (d(x_in) as bf16, the weight-gradient closures).  x2 = x_in +
-    [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2."""
+    [h | a_s] [W_proj | W2]^T + b_proj + dms2[tok] * b2.  ``fsum = (w [N], partial [frames, LN_FSUM_GROUPS, D])``: the ln_2
+    backward also leaves the per-frame sums of w[n] * d(x_in) (in token groups) in ``partial``."""
     dev = dyb.device
     M, D = dyb.shape
     r, H4 = fz.r, 4 * D
@@ -605,7 +616,10 @@ def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: 
     dxn = _empty((M, D), BF16, dev)
     ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
     dxb = _empty((M, D), BF16, dev)                  # (dcat stays alive in the D_fc1 weight-gradient closure)
-    ops.layernorm_bwd(dxn, x_in, fz.g2, mean2, rstd2, M, D, lddy=D, ldx=D, lddx=D, dres=dyb, dx_bf16=dxb)
+    if fsum is not None:
+        ops.layernorm_bwd_fsum(dxn, x_in, fz.g2, mean2, rstd2, dyb, dxb, fsum[0], fsum[1], M // N, N, D)
+    else:
+        ops.layernorm_bwd(dxn, x_in, fz.g2, mean2, rstd2, M, D, lddy=D, ldx=D, lddx=D, dres=dyb, dx_bf16=dxb)
     return dxb, big_later
 
 
@@ -631,15 +645,20 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     M, D = dyb.shape
     BT = B * T
     r, H4 = fz.r, 4 * D
+    # sum_n dms1[n] * d(x1)[frame, n, :] (the per-frame S_Adapter vector's gradient) comes out of the ln_2 backward itself
+    fpart = _empty((BT, ops.LN_FSUM_GROUPS, D), F32, dev) if _FSUM_IN_LN else None
     dx1b, big_later = _mlp_adapter_backward(dyb, c["x1"], c["mean2"], c["rstd2"], c["xn"], c["hcat_pre"], c["a_s"], c["dms2"],
-                                            fz, grads["MLP_Adapter"], N)
+                                            fz, grads["MLP_Adapter"], N, fsum=(c["dms1"], fpart) if _FSUM_IN_LN else None)
     # ---- x1 = x + oml[f] * (ao Wo^T + bo) + dms1[tok] * s_vec[f]
     # class-token chain (S_Adapter, cross term, T_Adapter; a dozen kernels on B*T rows) on the side stream ...
     later: list = big_later       # the adapters' weight gradients: nobody downstream waits for them
     ar = _Arena(dev, 48 * BT * D + (1 << 16))      # side-stream tensors live in main-stream memory (see _Arena)
     with _Fork(dev, "bwd") as fork:
         dsv = ar.take((BT, D), F32)
-        ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
+        if _FSUM_IN_LN:
+            ops.frame_sum(fpart, None, dsv, BT, ops.LN_FSUM_GROUPS, D)      # the groups' partial sums, in order
+        else:
+            ops.frame_sum(dx1b, c["dms1"], dsv, BT, N, D)
         # S_Adapter on the per-frame vector sin = lamda * crs ; crs = (xt Wv^T + bv) Wo^T + bo
         dsv_b = ar.take((BT, D), BF16)
         ops.cast_bf16(dsv, dsv_b)
@@ -663,6 +682,10 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
             ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv_cls, B, T, N, H, compact=True)
             dxl_cls = ar.take((BT, D), F32)
             ops.gemm(dqkv_cls, fz.WqkvT, ops.EPI_F32, dxl_cls)
+            if _DEFER_JOIN:     # ln_1 statistics of the class rows, gathered for the second, class-rows-only ln_1 backward below
+                m_cls, r_cls = ar.take((BT,), F32), ar.take((BT,), F32)
+                m_cls.copy_(c["mean1"].view(BT, N)[:, 0])
+                r_cls.copy_(c["rstd1"].view(BT, N)[:, 0])
     if keep is None:       # stand-alone use: the weight gradients are complete when this function returns
         keep = []
         fork.run_detached(later, keep)
@@ -682,11 +705,21 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     dxl = _empty((M, D), BF16, dev)
     ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
     del dqkv
+    dxb = _empty((M, D), BF16, dev)
+    if _LATE_JOIN and _DEFER_JOIN:
+        # ---- ln_1 over all rows WITHOUT the class-token chain's share of the class rows, then the join, then ln_1 again for
+        # the B*T class rows alone (LayerNorm backward is row-wise: same bits as adding first).  The chain is ~14 small
+        # kernels beside persistent GEMM / attention grids; joining before ln_1 left the main stream waiting for it
+        # (AIM_JOIN_STATS), joining after it hides ln_1's 0.15 ms per block of that.
+        ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
+        fork.join()
+        ops.add_rows(dxl, N * D, dxl_cls)       # class rows: rows n == 0 of every frame
+        ops.layernorm_bwd(dxl, c["x"], fz.g1, m_cls, r_cls, BT, D, lddy=N * D, ldx=N * D, lddx=N * D, dres=dx1b, dx_bf16=dxb)
+        return dxb
     if _LATE_JOIN:
         fork.join()
         ops.add_rows(dxl, N * D, dxl_cls)       # class rows: rows n == 0 of every frame
     # ---- ln_1
-    dxb = _empty((M, D), BF16, dev)
     ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
     return dxb
 

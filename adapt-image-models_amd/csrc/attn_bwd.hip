@@ -686,8 +686,13 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
             attr_set2 = true;
         }
         const int items = BT * H;
-        int cus = 256;
-        { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+        int cus = aim_stream_cus(st);
+        // The grid is persistent (one workgroup per CU for the whole launch): whatever runs beside it on another stream -- the
+        // class-token chain's dozen small kernels, which the main stream joins right after the next GEMM -- would not get a CU
+        // until the launch ends (measured: 1.3 ms of join stall per step with all 256 CUs taken, 0.16 ms with the two-kernel
+        // form).  A few CUs stay out of the grid; AIM_ATTN_PIPE_RESERVE overrides the count.
+        static const int reserve = [] { const char* e = getenv("AIM_ATTN_PIPE_RESERVE"); return e ? atoi(e) : 10; }();
+        if (reserve > 0 && items > cus - reserve && cus - reserve >= 8) cus -= reserve;
         static const int grid_cap = [] { const char* e = getenv("AIM_ATTN_PIPE_GRID"); return e ? atoi(e) : 0; }();   // tests: few workgroups, many items each
         if (grid_cap > 0 && grid_cap < cus) cus = grid_cap;
         const int grid = items < cus ? items : cus;

@@ -28,15 +28,6 @@
 #include "gemm_epilogue.h"
 #include <stdlib.h>
 
-static int aim_num_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus > 0 ? cus : 256;
-    }();
-    return n;
-}
-
 namespace {
 
 constexpr int HT = 128 * 64 * 2;        // half-tile bytes
@@ -369,7 +360,8 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     // a persistent grid that fills every CU starves whatever runs beside it on another stream: the caller can keep a few
     // CUs out of the grid while such work is in flight
     const int reserve = g.reserve_cus > 0 ? g.reserve_cus : 0;       // per-call knob (aim_gemm_args.reserve_cus)
-    const int cus = aim_num_cus() - reserve > 8 ? aim_num_cus() - reserve : 8;
+    const int ncu = aim_stream_cus(st);                     // the stream's CU mask, or the device
+    const int cus = ncu - reserve > 8 ? ncu - reserve : 8;
     int grid = tiles < cus ? tiles : cus;
     // balanced grid: the fewest workgroups that still finish in ceil(tiles / cus) rounds.  1 182 tiles take 5 rounds on 256
     // CUs and on 237: the 19 CUs that would idle through the last round are free for the other streams for the whole

@@ -134,6 +134,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     }
 }
 
+
+// ln_bwd_kernel for bf16 dy / dres / dx that ALSO emits per-frame weighted column sums of the dx it stores:
+//   partial[frame][g][c] = sum over the frame's token group g of w[n] * dx_bf16[frame*ntok + n][c].
+// The block backward needs sum_n dms1[n] * d(x1)[frame, n, :] for the per-frame S_Adapter vector path; taken here, from the
+// values in registers, it replaces a separate pass over the 155 MB tensor (aim_frame_sum) that opened the class-token chain
+// on the side stream and ran starved of CUs beside a persistent GEMM.  One workgroup = one (frame, token group); a wave walks
+// every fourth row of the group (the per-row arithmetic is ln_bwd_kernel's, bit for bit); the four waves' sums meet in LDS
+// in a fixed order, the G groups are summed by aim_frame_sum over the [frames][G][D] partials (fixed order: reproducible).
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_fsum_kernel(const bf16_t* __restrict__ dy, long long lddy,
+                                                          const float* __restrict__ x, long long ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                          bf16_t* __restrict__ dxb, long long lddx, const float* __restrict__ w,
+                                                          float* __restrict__ partial, int ntok, int G, int D) {
+    __shared__ f32x4 red[4][NC * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x / G, g = blockIdx.x - frame * G;
+    const int rg = (ntok + G - 1) / G;
+    const int n_end = min(ntok, (g + 1) * rg);
+    const int nch = D >> 2;
+    f32x4 fs[NC], gm[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        fs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ch = lane + c * 64;
+        gm[c] = ch < nch ? *(const f32x4*)(gamma + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int n = g * rg + wave; n < n_end; n += 4) {
+        const long long row = (long long)frame * ntok + n;
+        const float mu = mean[row], rs = rstd[row];
+        const float wt = w ? w[n] : 1.0f;
+        f32x4 gv[NC], xh[NC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                const bf16x4 db = *(const bf16x4*)(dy + row * lddy + ch * 4);
+                const f32x4 d = f32x4{(float)db[0], (float)db[1], (float)db[2], (float)db[3]};
+                const f32x4 xv = *(const f32x4*)(x + row * ldx + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[c][e] = (xv[e] - mu) * rs;
+                    gv[c][e] = d[e] * gm[c][e];
+                    s1 += gv[c][e];
+                    s2 += gv[c][e] * xh[c][e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gv[c][e] - m1 - xh[c][e] * m2);
+                const bf16x4 rb = *(const bf16x4*)(dres + row * lddx + ch * 4);
+                o += f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+                const bf16x4 ob = pack4(o[0], o[1], o[2], o[3]);
+                *(bf16x4*)(dxb + row * lddx + ch * 4) = ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fs[c][e] += wt * (float)ob[e];      // the STORED (bf16) value, like a pass over dx
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) red[wave][lane + c * 64] = fs[c];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < nch; ch += 256)
+        *(f32x4*)(partial + (long long)blockIdx.x * D + ch * 4) = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
+}
+
 }  // namespace
 
 extern "C" int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
@@ -226,5 +300,25 @@ extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, c
 #undef AIM_LN_BWD
 #undef AIM_LN_BWD_T
     AIM_CHECK_LAUNCH("aim_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int aim_layernorm_bwd_fsum(const aim_bf16* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                      const float* mean, const float* rstd, const aim_bf16* dres, aim_bf16* dx_bf16,
+                                      int64_t lddx, const float* w, float* fsum_partial, int groups, int frames, int ntok,
+                                      int D, void* stream) {
+    AIM_CHECK_ARG(frames > 0 && ntok > 0 && groups > 0 && D > 0 && (D % 4) == 0 && D <= 8 * 256,
+                  "layernorm_bwd_fsum: bad shape frames=%d ntok=%d groups=%d D=%d", frames, ntok, groups, D);
+    AIM_CHECK_ARG(dy && x && gamma && mean && rstd && dres && dx_bf16 && fsum_partial, "layernorm_bwd_fsum: null pointer");
+    AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd_fsum: strides must be multiples of 4");
+#define AIM_LN_FS(NC)                                                                                                  \
+    hipLaunchKernelGGL(ln_bwd_fsum_kernel<NC>, dim3(frames * groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, \
+                       (long long)lddy, x, (long long)ldx, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx_bf16,    \
+                       (long long)lddx, w, fsum_partial, ntok, groups, D)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_LN_FS(1); else if (nc == 2) AIM_LN_FS(2); else if (nc == 3) AIM_LN_FS(3);
+    else if (nc == 4) AIM_LN_FS(4); else AIM_LN_FS(8);
+#undef AIM_LN_FS
+    AIM_CHECK_LAUNCH("aim_layernorm_bwd_fsum");
     return 0;
 }

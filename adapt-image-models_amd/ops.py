@@ -228,6 +228,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=No
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
 
 
+LN_FSUM_GROUPS = 4      # token groups per frame of layernorm_bwd_fsum's partial sums
+
+
+def layernorm_bwd_fsum(dy, x, gamma, mean, rstd, dres, dx_bf16, w, partial, frames, ntok, D):
+    """layernorm_bwd for bf16 dy / dres / dx (contiguous rows) that also writes partial[frames, LN_FSUM_GROUPS, D]: the
+    per-frame sums of w[n] * dx over each token group; ``frame_sum(partial, None, out, frames, LN_FSUM_GROUPS, D)`` finishes."""
+    _chk(dy, BF16, "dy"); _chk(dres, BF16, "dres"); _chk(dx_bf16, BF16, "dx_bf16")
+    for n_, t_ in (("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("w", w), ("partial", partial)):
+        _chk(t_, F32, n_)
+    assert partial.numel() >= frames * LN_FSUM_GROUPS * D
+    check(load_library().aim_layernorm_bwd_fsum(dy.data_ptr(), D, x.data_ptr(), D, gamma.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), dres.data_ptr(), dx_bf16.data_ptr(), D, _p(w),
+                                                partial.data_ptr(), LN_FSUM_GROUPS, frames, ntok, D, _stream()),
+          "aim_layernorm_bwd_fsum")
+
+
 def attn_fwd(qkv, out, lse, BT, N, H):
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(lse, F32, "lse")
     check(load_library().aim_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BT, N, H, _stream()),

@@ -151,6 +151,14 @@ int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0
                       const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,
                       aim_bf16* dx_bf16, int64_t lddx, float* dgamma, float* dbeta,
                       int rows, int D, void* stream);
+/* The bf16 form of aim_layernorm_bwd (dy, dres, dx all bf16, rows = frames*ntok) that also emits per-frame weighted column
+ * sums of the dx it stores: fsum_partial[frame][g][c] = sum over token group g (ceil(ntok/groups) tokens) of
+ * w[n] * dx_bf16[frame*ntok + n][c]   (w NULL = 1).  aim_frame_sum(fsum_partial, f32, NULL, out, frames, groups, D) finishes
+ * it: the backward's sum_n dms1[n] d(x1)[frame, n, :] (autograd of the broadcast S_Adapter term, vit_clip.py:272-275)
+ * without a second pass over d(x1). */
+int aim_layernorm_bwd_fsum(const aim_bf16* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                           const float* mean, const float* rstd, const aim_bf16* dres, aim_bf16* dx_bf16, int64_t lddx,
+                           const float* w, float* fsum_partial, int groups, int frames, int ntok, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spatial multi-head self-attention over the N tokens of each frame (flash-style, scores never

@@ -132,6 +132,35 @@ def test_gemm_expsum_batched(N):
     close(got, ref, 1e-4, 1e-5, "expsum logsumexp")
 
 
+@pytest.mark.parametrize("frames,ntok,D", [(6, 197, 768), (3, 257, 1024), (5, 3, 64), (2, 50, 192)])
+def test_layernorm_bwd_fsum(frames, ntok, D):
+    """ln backward that also emits the per-frame weighted token sums of the dx it stores (the ln_2 backward of the block):
+    dx equal to aim_layernorm_bwd's within one bf16 ulp, the finished sums equal to a frame_sum pass over that dx."""
+    ops = _ops()
+    M = frames * ntok
+    x = rnd((M, D), 70, 2.0)
+    g = rnd((D,), 71, 1.0) + 1.0
+    dy = rnd((M, D), 72, 1.0, torch.bfloat16)
+    dres = rnd((M, D), 73, 1.0, torch.bfloat16)
+    w = torch.rand(ntok, device=DEV) * (torch.rand(ntok, device=DEV) > 0.3)       # DropPath-like factors, zeros included
+    mean, rstd = x.mean(1).contiguous(), (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    ref = torch.empty((M, D), dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, M, D, lddy=D, ldx=D, lddx=D, dres=dres, dx_bf16=ref)
+    want = torch.zeros((frames, D), device=DEV)
+    ops.frame_sum(ref, w, want, frames, ntok, D)
+    got_dx = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    part = torch.full((frames, ops.LN_FSUM_GROUPS, D), float("nan"), device=DEV)
+    ops.layernorm_bwd_fsum(dy, x, g, mean, rstd, dres, got_dx, w, part, frames, ntok, D)
+    got = torch.zeros((frames, D), device=DEV)
+    ops.frame_sum(part, None, got, frames, ops.LN_FSUM_GROUPS, D)
+    # same arithmetic, separately compiled (fp contraction may differ in the last bit): at most one bf16 ulp apart
+    close(got_dx, ref, 1e-6, 2 ** -7, "ln_bwd_fsum dx")
+    # the sums are over the values THIS kernel stored (a last-bit difference in dx is a whole bf16 ulp in one term)
+    direct = (got_dx.float().view(frames, ntok, D) * w.view(1, ntok, 1)).sum(1)
+    close(got, want, 2e-3 * float(want.abs().max()) + 1e-6, 1e-5, "ln_bwd_fsum frame sums vs the two-pass form")
+    close(got, direct, 1e-4 * float(direct.abs().max()) + 1e-6, 1e-5, "ln_bwd_fsum vs torch")
+
+
 # ------------------------------------------------------------------ LayerNorm ------------------
 @pytest.mark.parametrize("rows,D", [(7, 128), (1000, 768), (33, 1024)])
 def test_layernorm_fwd_bwd(rows, D):
