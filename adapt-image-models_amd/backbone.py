@@ -244,7 +244,6 @@ def join_stats():
 _USE_SIDE = os.environ.get("AIM_SIDE_STREAM", "1") != "0"
 _LAMBDA_ON_SIDE = os.environ.get("AIM_LAMBDA_SIDE", "1") != "0"
 _LATE_JOIN = os.environ.get("AIM_LATE_JOIN", "1") != "0"
-_DEFER_JOIN = os.environ.get("AIM_DEFER_JOIN", "1") != "0"     # (A/B switch) join the class-token chain after ln_1 backward
 _FSUM_IN_LN = os.environ.get("AIM_FSUM_IN_LN", "1") != "0"     # (A/B switch) per-frame d(x1) sums from the ln_2 backward
 _CLS_EARLY = os.environ.get("AIM_CLS_EARLY", "1") != "0"
 _LAMBDA_FUSED = os.environ.get("AIM_LAMBDA_FUSED", "1") != "0"
@@ -682,10 +681,6 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
             ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv_cls, B, T, N, H, compact=True)
             dxl_cls = ar.take((BT, D), F32)
             ops.gemm(dqkv_cls, fz.WqkvT, ops.EPI_F32, dxl_cls)
-            if _DEFER_JOIN:     # ln_1 statistics of the class rows, gathered for the second, class-rows-only ln_1 backward below
-                m_cls, r_cls = ar.take((BT,), F32), ar.take((BT,), F32)
-                m_cls.copy_(c["mean1"].view(BT, N)[:, 0])
-                r_cls.copy_(c["rstd1"].view(BT, N)[:, 0])
     if keep is None:       # stand-alone use: the weight gradients are complete when this function returns
         keep = []
         fork.run_detached(later, keep)
@@ -705,21 +700,11 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
     dxl = _empty((M, D), BF16, dev)
     ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
     del dqkv
-    dxb = _empty((M, D), BF16, dev)
-    if _LATE_JOIN and _DEFER_JOIN:
-        # ---- ln_1 over all rows WITHOUT the class-token chain's share of the class rows, then the join, then ln_1 again for
-        # the B*T class rows alone (LayerNorm backward is row-wise: same bits as adding first).  The chain is ~14 small
-        # kernels beside persistent GEMM / attention grids; joining before ln_1 left the main stream waiting for it
-        # (AIM_JOIN_STATS), joining after it hides ln_1's 0.15 ms per block of that.
-        ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
-        fork.join()
-        ops.add_rows(dxl, N * D, dxl_cls)       # class rows: rows n == 0 of every frame
-        ops.layernorm_bwd(dxl, c["x"], fz.g1, m_cls, r_cls, BT, D, lddy=N * D, ldx=N * D, lddx=N * D, dres=dx1b, dx_bf16=dxb)
-        return dxb
     if _LATE_JOIN:
         fork.join()
         ops.add_rows(dxl, N * D, dxl_cls)       # class rows: rows n == 0 of every frame
     # ---- ln_1
+    dxb = _empty((M, D), BF16, dev)
     ops.layernorm_bwd(dxl, c["x"], fz.g1, c["mean1"], c["rstd1"], M, D, lddy=D, ldx=D, lddx=D, dres=dx1b, dx_bf16=dxb)
     return dxb
 
