@@ -592,10 +592,13 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                     tc[dt] = lds_read_tr4(sO + swz_off(r0, ch) + half);
                     td[dt] = lds_read_tr4(sO + swz_off(r0 + 16, ch) + half);
                 }
-                bf16x8 pf[2], dsf[2];
+                bf16x8 pf[2] = {}, dsf[2] = {};
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
                     const int qrow = (2 * hs + w) * 16;
+                    // a 16-query tile wholly past N (the second half of the item's last 32-query step at N = 197) has zero
+                    // Q / dO rows and L = delta = 0: its P and dS contribute nothing, so its products and exps are skipped
+                    if (cur.qb * 64 + qrow >= N) continue;
                     bf16x8 qa[2], oa[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
