@@ -190,13 +190,14 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     // large-M problems run on the 256x256 pipelined kernel (gemm256.hip); AIM_GEMM_TILE=128 forces this file's.
     // Its epilogue moves 16 bytes per lane: bf16 outputs need N and the leading dimensions in multiples of 8.
     static const int pick = [] { const char* e = getenv("AIM_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    const bool wide_ok = (g.N % 8) == 0 && (g.n_split % 8) == 0 &&
+    // (and K in whole 64-element K-tiles: the 256x256 kernel's staging does not mask a row's K tail)
+    const bool wide_ok = (g.N % 8) == 0 && (g.n_split % 8) == 0 && (g.K % 64) == 0 &&
                          (epi == EPI_F32 ? ((g.ldr % 4) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128))
                                          : ((g.ldo % 8) == 0 && (epi != EPI_ACT || (g.ldo2 % 8) == 0) &&
                                             (epi != EPI_DACT || (g.ldaux % 8) == 0)));
     if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64 && wide_ok)
         return aim_gemm256_launch(g, epi, 1, st);
-    if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N)) {
+    if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N) && (g.K % 64) == 0) {
         AIM_CHECK_ARG(!g.xrow || (g.N < 256 && (g.ldx % 8) == 0), "gemm: EXPSUM extra key needs N < 256 and ldx %% 8 == 0");
         return aim_gemm256_launch(g, epi, batch, st);
     }

@@ -124,10 +124,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     auto seq_tile = [&](int seq) { return seq < nseq ? (seq / ncols) * tiles_n + c0 + seq % ncols : ntiles; };
     int seq = rank;
     TileSrc cur = make_tile<ES>(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
-    TileSrc nxt = make_tile<ES>(g, seq_tile(seq + wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+    // The next tile is kept as an index only: its descriptors and per-lane row offsets (8 VGPRs) are built in this tile's last
+    // K-iteration, when the staging state moves on to it -- held through the whole K-loop they pushed the kernel over 256 VGPRs.
+    int nxt_tile = seq_tile(seq + wg_per_group);
+    int nm0 = 0, nn0 = 0, nz = 0;
+    // (fp8 keeps the first scheme -- the next tile's staging state precomputed, the tile of a slot decided per piece: with its
+    //  8-register fragment tuples the just-in-time form spills 125 VGPRs and the inference GEMMs lose 7 %)
+    TileSrc nxt8 = cur;
+    if constexpr (F8) nxt8 = make_tile<ES>(g, nxt_tile, ntiles, tiles_n, tiles_m1, wave, srow, schunk);
 
-    // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi;  slot counts K-tiles from the start of the CURRENT tile
-    auto stage = [&](int buf, int which, int slot) {
+    // which: 0 A_lo, 1 A_hi, 2 B_lo, 3 B_hi.  One LDS-DMA piece costs ONE v_add: the K offset of the slot is added to the piece's
+    // row offset.  A row past M / N keeps an out-of-range offset (AIM_OOB + k0 < 2^32 stays past num_records); the K tail of a
+    // row is only masked when K is not a multiple of the K-tile (ktail, fp8 only: otherwise the chunk past K would read the next row).
+    // Stages that run into the NEXT tile (the look-ahead is at most two K-tiles: only in a tile's last K-iteration, after its
+    // last own stage) find the next tile's descriptors and row offsets already moved into `cur` -- the first version decided
+    // per piece which tile a slot belongs to (six VALU + two SALU instructions each, ~100 vector instructions per iteration
+    // beside the MFMAs).
+    constexpr bool ktail = false;          // the dispatcher sends K % 64 != 0 to the 128x128 kernel (fp8 masks per piece, below)
+    auto stage_from = [&](const __amdgpu_buffer_rsrc_t& rA_, const __amdgpu_buffer_rsrc_t& rW_, const __amdgpu_buffer_rsrc_t& rX_,
+                          const unsigned (&voA_)[2][2], const unsigned (&voW_)[2][2], int buf, int which, int kt) {
+#ifdef AIM_X_NOSTAGE
+        return;
+#endif
+        const unsigned k0b = (unsigned)(kt * KT * ES);
+        AIM_LDS char* dst = smem + buf * BUF + which * HT + wave * 2048;
+        const int h = which & 1;
+        const bool kout = ktail && (kt * KT + schunk * (16 / ES)) >= g.K;      // (lane-dependent only when ktail)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (which < 2) {
+                stage_piece(rA_, dst + j * 1024, kout ? AIM_OOB : voA_[h][j] + k0b);
+            } else {
+                stage_piece(rW_, dst + j * 1024, kout ? AIM_OOB : voW_[h][j] + k0b);
+                if constexpr (EPI == EPI_EXPSUM) {
+                    // the extra key: tile-local W row g.N comes from `xrow`.  Only the 8 lanes of that row take part
+                    // (EXEC-masked LDS-DMA writes only its active lanes' 16-byte slots), over the zero the piece above
+                    // left there; the wave that owns the row has ONE more vector-memory op per W stage (xw below).
+                    if (g.xrow && h * 128 + (wave * 2 + j) * 8 + srow == g.N)
+                        stage_piece(rX_, dst + j * 1024, kout ? AIM_OOB : (unsigned)(schunk * 16) + k0b);
+                }
+            }
+        }
+    };
+    // fp8: slot counts K-tiles from the start of the CURRENT tile; slots >= nkp belong to the next one
+    auto stage8 = [&](int buf, int which, int slot) {
 #ifdef AIM_X_NOSTAGE
         return;
 #endif
@@ -139,23 +179,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         const int h = which & 1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (which < 2) {
-                const unsigned vo = in_next ? nxt.voA[h][j] : cur.voA[h][j];
-                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * ES) : AIM_OOB;
-                stage_piece(in_next ? nxt.rA : cur.rA, dst + j * 1024, v);
-            } else {
-                const unsigned vo = in_next ? nxt.voW[h][j] : cur.voW[h][j];
-                const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * ES) : AIM_OOB;
-                stage_piece(in_next ? nxt.rW : cur.rW, dst + j * 1024, v);
-                if constexpr (EPI == EPI_EXPSUM) {
-                    // the extra key: tile-local W row g.N comes from `xrow`.  Only the 8 lanes of that row take part
-                    // (EXEC-masked LDS-DMA writes only its active lanes' 16-byte slots), over the zero the piece above
-                    // left there; the wave that owns the row has ONE more vector-memory op per W stage (xw below).
-                    if (g.xrow && h * 128 + (wave * 2 + j) * 8 + srow == g.N)
-                        stage_piece(in_next ? nxt.rX : cur.rX, dst + j * 1024, kin ? (unsigned)((schunk * 8 + k0) * 2) : AIM_OOB);
-                }
-            }
+            const unsigned vo = which < 2 ? (in_next ? nxt8.voA[h][j] : cur.voA[h][j]) : (in_next ? nxt8.voW[h][j] : cur.voW[h][j]);
+            const unsigned v = (kin && vo != AIM_OOB) ? vo + (unsigned)(k0 * ES) : AIM_OOB;
+            if (which < 2) stage_piece(in_next ? nxt8.rA : cur.rA, dst + j * 1024, v);
+            else stage_piece(in_next ? nxt8.rW : cur.rW, dst + j * 1024, v);
         }
+    };
+    // slot `slot` of the current tile (fp8) = K-tile `kt` of the tile whose staging state `cur` holds (bf16)
+    auto stage = [&](int buf, int which, int slot, int kt) {
+        if constexpr (F8) stage8(buf, which, slot);
+        else stage_from(cur.rA, cur.rW, cur.rX, cur.voA, cur.voW, buf, which, kt);
     };
 
     f32x4 acc[8][4];
@@ -240,8 +273,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 #define AIM_VM4() do { if (xw) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F74); } while (0)
 
     // prologue (first tile only): K-tile 0 complete, three half-tiles of K-tile 1 in flight
-    stage(0, 2, 0); stage(0, 3, 0); stage(0, 0, 0); stage(0, 1, 0);
-    stage(1, 2, 1); stage(1, 3, 1);
+    stage(0, 2, 0, 0); stage(0, 3, 0, 0); stage(0, 0, 0, 0); stage(0, 1, 0, 0);
+    stage(1, 2, 1, 1); stage(1, 3, 1, 1);
     AIM_VM4();
     AIM_BAR();
     // The two wave groups (wm = 0 | 1; one wave of each per SIMD) run ONE BARRIER apart: while one group issues its
@@ -282,6 +315,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         // Slots >= nkp run into the NEXT tile's K-tiles (cross-tile prefetch).
         for (int it = 0; it < nkp / 2; ++it) {
             const int te = 2 * it, to = te + 1;
+            // the K-tiles te+2 / to+2 staged in this iteration belong to the next tile in the last iteration (its tiles 0 / 1)
+            const bool lastit = it == nkp / 2 - 1;
+            const int kt_e = lastit ? 0 : te + 2, kt_o = lastit ? 1 : to + 2;
             // fp8: the launcher guarantees an even number of K-tiles, so no fragment read / MFMA is conditional (a
             // conditionally refilled 8-register fragment tuple costs copies and spills)
             const bool odd_live = F8 ? true : (to < nk);
@@ -290,26 +326,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
 #endif
             AIM_STAMP(0);
             read_b(0); read_a(0, 0);                               // ---- Ra
-            stage(1, 0, to); stage(1, 1, to);
+            stage(1, 0, to, to); stage(1, 1, to, to);
+            if (!F8 && lastit) {    // this tile's last own stage is out: the staging state moves on to the next tile
+                const TileSrc t = make_tile<ES>(g, nxt_tile, ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+                cur.rA = t.rA;
+                cur.rW = t.rW;
+                cur.rX = t.rX;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        cur.voA[h][j] = t.voA[h][j];
+                        cur.voW[h][j] = t.voW[h][j];
+                    }
+                nm0 = t.m0;         // (the epilogue below still needs THIS tile's coordinates in cur.m0 / n0 / z)
+                nn0 = t.n0;
+                nz = t.z;
+            }
             AIM_LGKM0();
             AIM_STAMP(1); AIM_BAR(); AIM_STAMP(2);
             mma(0, 0); mma(0, 2);
             AIM_STAMP(3); AIM_BAR(); AIM_STAMP(4);
             read_a(0, 1);                                          // ---- Rb
-            stage(0, 2, te + 2); stage(0, 3, te + 2);
+            stage(0, 2, te + 2, kt_e); stage(0, 3, te + 2, kt_e);
             AIM_VM4();
             AIM_LGKM0();
             AIM_STAMP(5); AIM_BAR(); AIM_STAMP(6);
             mma(1, 2); mma(1, 0);
             AIM_STAMP(7); AIM_BAR(); AIM_STAMP(8);
             if (odd_live) { read_b(1); read_a(1, 0); }             // ---- Rc
-            stage(0, 0, te + 2); stage(0, 1, te + 2);
+            stage(0, 0, te + 2, kt_e); stage(0, 1, te + 2, kt_e);
             AIM_LGKM0();
             AIM_STAMP(9); AIM_BAR(); AIM_STAMP(10);
             if (odd_live) { mma(0, 0); mma(0, 2); }
             AIM_STAMP(11); AIM_BAR(); AIM_STAMP(12);
             if (odd_live) read_a(1, 1);                            // ---- Rd
-            stage(1, 2, to + 2); stage(1, 3, to + 2);
+            stage(1, 2, to + 2, kt_o); stage(1, 3, to + 2, kt_o);
             AIM_VM4();
             AIM_LGKM0();
             AIM_STAMP(13); AIM_BAR(); AIM_STAMP(14);
@@ -343,8 +395,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
             }
             ++probe_i;
         }
-        cur = nxt;
-        nxt = make_tile<ES>(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+        if constexpr (F8) {
+            cur = nxt8;
+            nxt8 = make_tile<ES>(g, seq_tile(seq + 2 * wg_per_group), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+        } else {
+            cur.m0 = nm0;
+            cur.n0 = nn0;
+            cur.z = nz;
+            nxt_tile = seq_tile(seq + 2 * wg_per_group);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill stages of the tail
 }

@@ -203,6 +203,10 @@ template <int EPI, bool WS = false>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8][4], AIM_LDS char* scr, int m_base_in,
                                               int n_base_in, int lane) {
     const int m_base = __builtin_amdgcn_readfirstlane(m_base_in), n_base = __builtin_amdgcn_readfirstlane(n_base_in);
+    // The lane id is laundered so that nothing derived from it here (scratch addresses, row / column offsets, masks) is
+    // loop-invariant for the persistent tile loop: hoisted above the K-loop, which runs at the 256-VGPR limit, those values
+    // are spilled, and a scratch reload waits on vmcnt behind the next tile's LDS-DMA.
+    asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fq = lane >> 4;
     // half of one 16-row MFMA tile -> scratch rows 0..7 (the lanes holding the other half sit out)
     auto dump8 = [&](int mt, int half) {
