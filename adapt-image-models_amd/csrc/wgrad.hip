@@ -59,21 +59,29 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const bf16_t* __restrict__ G
     aim_rsrc_words rG = make_rsrc_words(Gb, ((long long)(rows - 1) * ldg + min(TILE, Nw - n0)) * 2);
     aim_rsrc_words rA = make_rsrc_words(Ab, ((long long)(rows - 1) * lda + min(TILE, Kw - k0)) * 2);
 
-    // staging: per operand 16 pieces (4 column images x 4 row groups of 8); a wave takes 2 of each
+    // staging: per operand 16 pieces (4 column images x 4 row groups of 8); a wave takes 2 of each.  A piece's offset is its
+    // stage-0 offset plus ms * (32 rows): one v_add per piece and step.  Rows past the chunk need no test -- the resources end
+    // with the chunk's last row, so their offsets are out of range by themselves (zero fill); columns past Nw / Kw carry
+    // AIM_OOB from the start (AIM_OOB + ms * step stays out of range).
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    unsigned vg0[2], va0[2];
+    AIM_LDS char* pdst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wave * 2 + j;           // 0..15
+        const int img = piece >> 2, rg = piece & 3;
+        const int r = rg * 8 + srow;              // row inside stage 0
+        const int col = img * 64 + schunk * 8;
+        vg0[j] = n0 + col < Nw ? (unsigned)((r * ldg + col) * 2) : AIM_OOB;
+        va0[j] = k0 + col < Kw ? (unsigned)((r * lda + col) * 2) : AIM_OOB;
+        pdst[j] = smem + img * IMG + rg * 1024;
+    }
+    const unsigned gstep = (unsigned)(MSTEP * ldg * 2), astep = (unsigned)(MSTEP * lda * 2);
     auto stage = [&](int buf, int ms) {
-        AIM_LDS char* dG = smem + buf * STAGE_BYTES;
-        AIM_LDS char* dA = dG + OPER_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int piece = wave * 2 + j;           // 0..15
-            const int img = piece >> 2, rg = piece & 3;
-            const int r = ms * MSTEP + rg * 8 + srow;  // row inside the chunk
-            const int col = img * 64 + schunk * 8;
-            const unsigned vg = (r < rows && n0 + col < Nw) ? (unsigned)((r * ldg + col) * 2) : AIM_OOB;
-            const unsigned va = (r < rows && k0 + col < Kw) ? (unsigned)((r * lda + col) * 2) : AIM_OOB;
-            stage_piece_asm(rG, dG + img * IMG + rg * 1024, vg);
-            stage_piece_asm(rA, dA + img * IMG + rg * 1024, va);
+            stage_piece_asm(rG, pdst[j] + buf * STAGE_BYTES, vg0[j] + (unsigned)ms * gstep);
+            stage_piece_asm(rA, pdst[j] + buf * STAGE_BYTES + OPER_BYTES, va0[j] + (unsigned)ms * astep);
         }
     };
 
