@@ -142,27 +142,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 // on the side stream and ran starved of CUs beside a persistent GEMM.  One workgroup = one (frame, token group); a wave walks
 // every fourth row of the group (the per-row arithmetic is ln_bwd_kernel's, bit for bit); the four waves' sums meet in LDS
 // in a fixed order, the G groups are summed by aim_frame_sum over the [frames][G][D] partials (fixed order: reproducible).
+// launch_bounds (256, 6) + a wave-uniform row index (scalar address arithmetic): left alone the compiler spends 98 VGPRs
+// (4 waves per SIMD) and the kernel runs at 4.8 TB/s; now 70 VGPRs, 7 waves per SIMD.
 template <int NC>
-__global__ __launch_bounds__(256) void ln_bwd_fsum_kernel(const bf16_t* __restrict__ dy, long long lddy,
+__global__ __launch_bounds__(256, (NC <= 4 ? 6 : 2)) void ln_bwd_fsum_kernel(const bf16_t* __restrict__ dy, long long lddy,
                                                           const float* __restrict__ x, long long ldx,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                           bf16_t* __restrict__ dxb, long long lddx, const float* __restrict__ w,
                                                           float* __restrict__ partial, int ntok, int G, int D) {
     __shared__ f32x4 red[4][NC * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform rows: scalar address arithmetic
     const int frame = blockIdx.x / G, g = blockIdx.x - frame * G;
     const int rg = (ntok + G - 1) / G;
     const int n_end = min(ntok, (g + 1) * rg);
     const int nch = D >> 2;
-    f32x4 fs[NC], gm[NC];
+    f32x4 fs[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        fs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ch = lane + c * 64;
-        gm[c] = ch < nch ? *(const f32x4*)(gamma + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int c = 0; c < NC; ++c) fs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
     for (int n = g * rg + wave; n < n_end; n += 4) {
+        asm volatile("" ::: "memory");          // one row at a time: no loads of the next row hoisted into this one (registers)
         const long long row = (long long)frame * ntok + n;
         const float mu = mean[row], rs = rstd[row];
         const float wt = w ? w[n] : 1.0f;
@@ -175,10 +176,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fsum_kernel(const bf16_t* __restri
                 const bf16x4 db = *(const bf16x4*)(dy + row * lddy + ch * 4);
                 const f32x4 d = f32x4{(float)db[0], (float)db[1], (float)db[2], (float)db[3]};
                 const f32x4 xv = *(const f32x4*)(x + row * ldx + ch * 4);
+                const f32x4 gm = *(const f32x4*)(gamma + ch * 4);      // (L1-resident; held across rows it costs 12 VGPRs)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[c][e] = (xv[e] - mu) * rs;
-                    gv[c][e] = d[e] * gm[c][e];
+                    gv[c][e] = d[e] * gm[e];
                     s1 += gv[c][e];
                     s2 += gv[c][e] * xh[c][e];
                 }

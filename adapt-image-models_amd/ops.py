@@ -228,7 +228,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, D, *, lddy, ldx, lddx, dres=No
                                            _p(dgamma), _p(dbeta), rows, D, _stream()), "aim_layernorm_bwd")
 
 
-LN_FSUM_GROUPS = 4      # token groups per frame of layernorm_bwd_fsum's partial sums
+LN_FSUM_GROUPS = 13     # token groups per frame of layernorm_bwd_fsum's partial sums (16 tokens at 197: 4 rows per wave;
+                        # with 4 groups the 2 048 workgroups ran as one full round and a nearly empty one)
 
 
 def layernorm_bwd_fsum(dy, x, gamma, mean, rstd, dres, dx_bf16, w, partial, frames, ntok, D):
