@@ -10,7 +10,8 @@ tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='ta
 kd = [t for t in tabs if "kernel_dispatch" in t][0]
 ks = [t for t in tabs if "kernel_symbol" in t][0]
 rows = list(cur.execute(f"select d.start, d.end, d.queue_id, s.display_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-idx = [i for i, r in enumerate(rows) if "attn_bwd_pipe" in r[3] or "attn_bwd_dq" in r[3]]
+key = sys.argv[2] if len(sys.argv) > 2 else "attn_bwd_pipe"
+idx = [i for i, r in enumerate(rows) if key in r[3] and "cls_" not in r[3]]
 a, b = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
 t0 = rows[a][0]
 short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:44]

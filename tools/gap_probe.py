@@ -3,13 +3,15 @@
 
 usage: gap_probe.py <run_results.db>
 The trace's stream ids do not separate the HIP streams reliably, so the chain is picked by kernel name: the large GEMMs,
-LayerNorm and attention kernels only ever run on the main stream, in dependency order."""
+LayerNorm and attention kernels run on the main stream in dependency order.  Caveat: the forward's class-token chain launches
+the SAME ln_fwd kernel on its 512 class rows on the side stream, so "ln_fwd -> X" pairs mix in side-stream launches (the
+negative ln_fwd -> ln_fwd entry is that overlap); tools/chain_probe.py shows the true per-block timeline."""
 import collections
 import re
 import sqlite3
 import sys
 
-MAIN = re.compile(r"gemm256_kernel|ln_fwd_kernel|ln_bwd_kernel|attn_fwd_kernel|attn_bwd_|embed_ln|embed_bwd_kernel|patchify")
+MAIN = re.compile(r"gemm256_kernel|ln_fwd_kernel|ln_bwd_kernel|ln_bwd_fsum|[^s]_attn_fwd_kernel|^void \(anonymous namespace\)::attn_fwd|::attn_bwd_|embed_ln|embed_bwd_kernel|patchify")
 
 
 def main():
