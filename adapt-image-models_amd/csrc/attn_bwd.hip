@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                // the dP accumulators start from -delta (this lane's query): dS = P o (dP - delta) without the subtraction
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{-dl, -dl, -dl, -dl};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 kf = lds_read8(sK + swz_off(t * 16 + frow, ks * 4 + fq));
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p = __builtin_amdgcn_exp2f(s[e] * C2 - L2);
-                    dsf[u * 4 + e] = (bf16_t)(p * (dp[e] - dl));
+                    dsf[u * 4 + e] = (bf16_t)(p * dp[e]);
                 }
             }
 #pragma unroll
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         }
         for (int i = tid; i < nq32; i += 256) {
             sL[i] = i < N ? lse[((long long)bt * H + h) * N + i] * LOG2E : 0.f;
-            sD[i] = i < N ? delta[((long long)bt * H + h) * N + i] : 0.f;
+            sD[i] = i < N ? -delta[((long long)bt * H + h) * N + i] : 0.f;      // negated: the dP accumulators start from it
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             for (int w = 0; w < 2; ++w) {  // the two 16-query tiles of this step
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 dp = f32x4{cur.Dr[w][0], cur.Dr[w][1], cur.Dr[w][2], cur.Dr[w][3]};       // -delta
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.qa[w][ks], kf[u][ks], s, 0, 0, 0);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                     for (int e = 0; e < 4; ++e) {
                         const float p = __builtin_amdgcn_exp2f(s[e] * C2 - cur.Lr[w][e]);
                         pf[u][w * 4 + e] = (bf16_t)p;
-                        dsf[u][w * 4 + e] = (bf16_t)(p * (dp[e] - cur.Dr[w][e]));
+                        dsf[u][w * 4 + e] = (bf16_t)(p * dp[e]);
                     }
                 }
             }
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
             dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0xB1, 0xF, 0xF, true));
             dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x4E, 0xF, 0xF, true));
             dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x141, 0xF, 0xF, true));
-            if ((lane & 7) == 0) sl[64 + g * 8 + srow] = p.qb * 64 + g * 8 + srow < N ? dl : 0.f;
+            // stored NEGATED: the producers start the dP accumulators from -delta, so dS = P o dP needs no subtraction
+            if ((lane & 7) == 0) sl[64 + g * 8 + srow] = p.qb * 64 + g * 8 + srow < N ? -dl : 0.f;
         }
         sl[lane] = p.qb * 64 + lane < N ? lreg * LOG2E : 0.f;
     };
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                     const f32x4 Dr = *(const AIM_LDS f32x4*)(sD + qrow + fq * 4);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = Dr;        // Dr = -delta: dP - delta comes out of the MFMA
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[u][ks], s, 0, 0, 0);
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                         for (int e = 0; e < 4; ++e) {
                             const float p = __builtin_amdgcn_exp2f(s[e] * C2 - Lr[e]);
                             pf[u][w * 4 + e] = (bf16_t)p;
-                            const bf16_t d = (bf16_t)(p * (dp[e] - Dr[e]));
+                            const bf16_t d = (bf16_t)(p * dp[e]);
                             dsf[u][w * 4 + e] = d;
                             ds4[e] = d;
                         }
