@@ -150,9 +150,11 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 // here), i.e. half cache lines: BF16 epilogue 3.9 -> 3.4 us but F32 12 -> 17 us, DACT 11 -> 13 us and a longer
 // store drain in the next tile's K-loop; whole step 1012 -> 962 clips/s.  Full-line row segments win.
 // ------------------------------------------------------------------------------------------------
-constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad
-constexpr int EPI_ROWFAC = 8 * EPI_RS;           // offset of the per-row factor table: 128 rows x {rs, vs}
-constexpr int EPI_SCRATCH = 8 * EPI_RS + 128 * 8;   // bytes per wave (fits beside the K-loop images)
+constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad (8-row fp32 sub-passes)
+constexpr int EPI_RSH = 144;                     // scratch row stride: 64 bf16 + 16 B pad (16-row bf16 sub-passes)
+constexpr int EPI_ROWFAC = 16 * EPI_RSH;         // offset of the per-row factor table: 128 rows x {rs, vs}  (>= 8 * EPI_RS)
+constexpr int EPI_SCRATCH = EPI_ROWFAC + 128 * 8;   // bytes per wave (fits beside the K-loop images)
+static_assert(16 * EPI_RSH >= 8 * EPI_RS, "the fp32 sub-pass scratch must fit in front of the row-factor table");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifndef AIM_STORE_POLICY
@@ -246,8 +248,92 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         }
     }
 
-    if constexpr (EPI != EPI_F32) {
-        // bf16 outputs (BF16 / ACT / DACT): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_ACT) {
+        // bf16 outputs without a second input (BF16, ACT): bias, row factor, activation and the cast to bf16 are applied in
+        // the MFMA layout (lane = row frow, 4 consecutive columns per 16-column tile), and a whole 16-row tile of bf16 values
+        // crosses the scratch at a time: every lane writes (no exec mask), half the LDS bytes of the fp32 sub-passes below and
+        // half as many round trips (stamped with the stores compiled out: the fp32 form spent 3.5 us of a BF16 tile's 3.75 us
+        // in these round trips, not in the stores).  Same arithmetic per element as before: bit-identical results.
+        // A wave's DS instructions execute in order, so neither the reads after the writes nor the next tile's writes after
+        // these reads need a wait; the empty asm statements only pin the compiler's order.
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const bool ncol = c8 < cols_left;
+        const __amdgpu_buffer_rsrc_t rOut =
+            epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 2, (long long)rows_left * g.ldo * 2);
+        const __amdgpu_buffer_rsrc_t rOut2 = epi_rsrc(EPI == EPI_ACT ? g.out2 : nullptr,
+                                                      ((long long)m_base * g.ldo2 + n_base) * 2, (long long)rows_left * g.ldo2 * 2);
+        f32x4 bj[4], wsj[4];
+        bool qg[4], rson[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = j * 16 + fq * 4;                       // the lane's columns of tile j (tile-local)
+            const unsigned vb = cj < cols_left ? (unsigned)cj * 4u : AIM_OOB;
+            bj[j] = buf_load_f4(rBias, vb);
+            wsj[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (WS) wsj[j] = buf_load_f4(epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff), vb);
+            qg[j] = col_act(g, n_base + cj) == ACT_QGELU;
+            rson[j] = EPI == EPI_BF16 || g.n_split == 0 || n_base + cj >= g.n_split;
+        }
+        unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * 2u : AIM_OOB;
+        unsigned voO2 = ncol ? (unsigned)(r8 * g.ldo2 + c8) * 2u : AIM_OOB;
+        const unsigned stO = (unsigned)g.ldo * 16u, stO2 = (unsigned)g.ldo2 * 16u;        // 8 rows of bf16
+        AIM_LDS char* wr = scr + frow * EPI_RSH + fq * 8;          // + j * 32: the lane's 4 columns of tile j
+        const AIM_LDS char* rd = scr + r8 * EPI_RSH + c8 * 2;      // rows r8 and r8 + 8, 8 columns
+        auto cross = [&](const bf16x4 (&t)[4], __amdgpu_buffer_rsrc_t r, unsigned& vo, unsigned st) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(AIM_LDS bf16x4*)(wr + j * 32) = t[j];
+            asm volatile("" ::: "memory");
+            const bf16x8 x0 = *(const AIM_LDS bf16x8*)rd;
+            const bf16x8 x1 = *(const AIM_LDS bf16x8*)(rd + 8 * EPI_RSH);
+            buf_store16(r, vo, x0);
+            epi_advance(vo, st);
+            buf_store16(r, vo, x1);
+            epi_advance(vo, st);
+        };
+        // ALLQ: every column of this wave tile takes QuickGELU (all but the adapter's column tile of the fused c_fc GEMM):
+        // decided once per tile with a ballot, so the sub-passes carry no per-lane activation branch
+        auto run16 = [&](auto ROWF, auto ALLQ) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float rs = 1.0f;
+                if constexpr (decltype(ROWF)::value) rs = rowfac[(i * 16 + frow) * 2];
+                bf16x4 o[4], pre[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (WS) v[e] = acc[i][j][e] * wsj[j][e] + bj[j][e];
+                        else v[e] = acc[i][j][e] + bj[j][e];
+                    }
+                    const float rsj = rson[j] ? rs : 1.0f;
+                    if constexpr (EPI == EPI_BF16) {
+                        o[j] = pack4(rsj * v[0], rsj * v[1], rsj * v[2], rsj * v[3]);
+                    } else {
+                        pre[j] = pack4(v[0], v[1], v[2], v[3]);
+                        if (decltype(ALLQ)::value || qg[j]) {
+                            const f32x2 y0 = quick_gelu2(f32x2{(float)pre[j][0], (float)pre[j][1]}) * rsj;
+                            const f32x2 y1 = quick_gelu2(f32x2{(float)pre[j][2], (float)pre[j][3]}) * rsj;
+                            o[j] = pack4(y0[0], y0[1], y1[0], y1[1]);
+                        } else {
+                            o[j] = pack4(rsj * gelu_erf((float)pre[j][0]), rsj * gelu_erf((float)pre[j][1]),
+                                         rsj * gelu_erf((float)pre[j][2]), rsj * gelu_erf((float)pre[j][3]));
+                        }
+                    }
+                }
+                cross(o, rOut, voO, stO);
+                if constexpr (EPI == EPI_ACT) cross(pre, rOut2, voO2, stO2);
+            }
+        };
+        const bool allq = EPI == EPI_ACT && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
+        if (rowf) {
+            if (allq) run16(std::true_type{}, std::true_type{}); else run16(std::true_type{}, std::false_type{});
+        } else {
+            if (allq) run16(std::false_type{}, std::true_type{}); else run16(std::false_type{}, std::false_type{});
+        }
+    } else if constexpr (EPI != EPI_F32) {
+        // bf16 / fp8 outputs with a second input or a narrower store (DACT, ACT8): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
         // global access is a 16-byte-per-lane, whole-128-B-row-segment instruction (the 8-byte form is
         // store-issue-bound).  N and the leading dimensions are multiples of 8 here (checked by the launcher).
         // DACT's saved pre-activations are prefetched one 32-row group ahead.
