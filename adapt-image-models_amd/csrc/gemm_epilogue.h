@@ -248,7 +248,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         }
     }
 
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_ACT) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_ACT || EPI == EPI_DACT) {
         // bf16 outputs without a second input (BF16, ACT): bias, row factor, activation and the cast to bf16 are applied in
         // the MFMA layout (lane = row frow, 4 consecutive columns per 16-column tile), and a whole 16-row tile of bf16 values
         // crosses the scratch at a time: every lane writes (no exec mask), half the LDS bytes of the fp32 sub-passes below and
@@ -262,6 +262,21 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 2, (long long)rows_left * g.ldo * 2);
         const __amdgpu_buffer_rsrc_t rOut2 = epi_rsrc(EPI == EPI_ACT ? g.out2 : nullptr,
                                                       ((long long)m_base * g.ldo2 + n_base) * 2, (long long)rows_left * g.ldo2 * 2);
+        const __amdgpu_buffer_rsrc_t rAux = epi_rsrc(EPI == EPI_DACT ? g.aux : nullptr,
+                                                     ((long long)m_base * g.ldaux + n_base) * 2, (long long)rows_left * g.ldaux * 2);
+        unsigned voA = ncol ? (unsigned)(r8 * g.ldaux + c8) * 2u : AIM_OOB;
+        const unsigned stA = (unsigned)g.ldaux * 16u;
+        // DACT: the saved pre-activations come in row segments (8 rows x 128 B per load) and cross the scratch the other
+        // way, into the MFMA layout, one 16-row tile ahead of their use
+        bf16x8 ax[3][2] = {};           // three tiles in flight (a tile is ~1 us of work, a load 2-3 us under load)
+        auto load_aux16 = [&](int slot) {
+            if constexpr (EPI == EPI_DACT) {
+                ax[slot][0] = buf_load_h8(rAux, voA);
+                epi_advance(voA, stA);
+                ax[slot][1] = buf_load_h8(rAux, voA);
+                epi_advance(voA, stA);
+            }
+        };
         f32x4 bj[4], wsj[4];
         bool qg[4], rson[4];
 #pragma unroll
@@ -272,7 +287,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             wsj[j] = f32x4{1.f, 1.f, 1.f, 1.f};
             if constexpr (WS) wsj[j] = buf_load_f4(epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff), vb);
             qg[j] = col_act(g, n_base + cj) == ACT_QGELU;
-            rson[j] = EPI == EPI_BF16 || g.n_split == 0 || n_base + cj >= g.n_split;
+            rson[j] = EPI == EPI_BF16 || g.n_split == 0 || n_base + cj >= g.n_split;       // (ACT / DACT: adapter columns only)
         }
         unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * 2u : AIM_OOB;
         unsigned voO2 = ncol ? (unsigned)(r8 * g.ldo2 + c8) * 2u : AIM_OOB;
@@ -294,11 +309,23 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         // ALLQ: every column of this wave tile takes QuickGELU (all but the adapter's column tile of the fused c_fc GEMM):
         // decided once per tile with a ballot, so the sub-passes carry no per-lane activation branch
         auto run16 = [&](auto ROWF, auto ALLQ) {
+            load_aux16(0);
+            load_aux16(1);
+            load_aux16(2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float rs = 1.0f;
                 if constexpr (decltype(ROWF)::value) rs = rowfac[(i * 16 + frow) * 2];
                 bf16x4 o[4], pre[4];
+                if constexpr (EPI == EPI_DACT) {       // this tile's pre-activations: row segments -> MFMA layout (pre[j])
+                    asm volatile("" ::: "memory");
+                    *(AIM_LDS bf16x8*)(scr + r8 * EPI_RSH + c8 * 2) = ax[i % 3][0];
+                    *(AIM_LDS bf16x8*)(scr + (r8 + 8) * EPI_RSH + c8 * 2) = ax[i % 3][1];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pre[j] = *(const AIM_LDS bf16x4*)(wr + j * 32);
+                    if (i + 3 < 8) load_aux16(i % 3);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v;
@@ -310,6 +337,16 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     const float rsj = rson[j] ? rs : 1.0f;
                     if constexpr (EPI == EPI_BF16) {
                         o[j] = pack4(rsj * v[0], rsj * v[1], rsj * v[2], rsj * v[3]);
+                    } else if constexpr (EPI == EPI_DACT) {
+                        if (decltype(ALLQ)::value || qg[j]) {
+                            const f32x2 d0 = quick_gelu_grad2(f32x2{(float)pre[j][0], (float)pre[j][1]});
+                            const f32x2 d1 = quick_gelu_grad2(f32x2{(float)pre[j][2], (float)pre[j][3]});
+                            const f32x2 y0 = (f32x2{v[0], v[1]} * rsj) * d0, y1 = (f32x2{v[2], v[3]} * rsj) * d1;
+                            o[j] = pack4(y0[0], y0[1], y1[0], y1[1]);
+                        } else {
+                            o[j] = pack4(rsj * v[0] * gelu_erf_grad((float)pre[j][0]), rsj * v[1] * gelu_erf_grad((float)pre[j][1]),
+                                         rsj * v[2] * gelu_erf_grad((float)pre[j][2]), rsj * v[3] * gelu_erf_grad((float)pre[j][3]));
+                        }
                     } else {
                         pre[j] = pack4(v[0], v[1], v[2], v[3]);
                         if (decltype(ALLQ)::value || qg[j]) {
@@ -326,14 +363,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 if constexpr (EPI == EPI_ACT) cross(pre, rOut2, voO2, stO2);
             }
         };
-        const bool allq = EPI == EPI_ACT && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
+        const bool allq = EPI != EPI_BF16 && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
         if (rowf) {
             if (allq) run16(std::true_type{}, std::true_type{}); else run16(std::true_type{}, std::false_type{});
         } else {
             if (allq) run16(std::false_type{}, std::true_type{}); else run16(std::false_type{}, std::false_type{});
         }
     } else if constexpr (EPI != EPI_F32) {
-        // bf16 / fp8 outputs with a second input or a narrower store (DACT, ACT8): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
+        // fp8 output (ACT8; the fp32-scratch form, which also still serves as the reference for the branch above): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
         // global access is a 16-byte-per-lane, whole-128-B-row-segment instruction (the 8-byte form is
         // store-issue-bound).  N and the leading dimensions are multiples of 8 here (checked by the launcher).
         // DACT's saved pre-activations are prefetched one 32-row group ahead.
