@@ -204,14 +204,28 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const TDX* __restrict__ 
     }
 }
 
-// dtemporal[t][c] += sum over the blocks' partial rows, in block order
+// dtemporal[t][c] += sum over the blocks' partial rows, in a fixed order: 64 columns x 4 row groups per workgroup, eight loads in
+// flight per thread (the first version walked the 256 partial rows one dependent load at a time: 114 us)
 __global__ __launch_bounds__(256) void embed_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dtemporal,
                                                                int chunks, int D) {
-    const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= D) return;
+    __shared__ float red[4][64];
+    const int t = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < D;
+    const float* p = partial + (long long)t * chunks * D + (live ? c : 0);
     float a = 0.f;
-    for (int y = 0; y < chunks; ++y) a += partial[((long long)t * chunks + y) * D + c];
-    dtemporal[(long long)t * D + c] += a;
+    int y = g;
+    for (; y + 28 < chunks; y += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(y + 4 * u) * D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; y < chunks; y += 4) a += p[(long long)y * D];
+    red[g][cl] = a;
+    __syncthreads();
+    if (g == 0 && live) dtemporal[(long long)t * D + c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // out[frame][d] = sum_tok w[tok] x[frame][tok][d].  Block (frame, 64-column group): 4 token groups x 64 float4-columns; a
@@ -514,7 +528,7 @@ extern "C" int aim_embed_bwd(const void* dx, int dx_is_bf16, const aim_bf16* tok
 #undef AIM_EB
     AIM_CHECK_LAUNCH("aim_embed_bwd");
     if (partial) {
-        hipLaunchKernelGGL(embed_bwd_finish_kernel, dim3(T, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, dtemporal,
+        hipLaunchKernelGGL(embed_bwd_finish_kernel, dim3(T, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, dtemporal,
                            chunks, D);
         AIM_CHECK_LAUNCH("aim_embed_bwd(finish)");
     }

@@ -246,24 +246,51 @@ extern "C" int aim_layernorm_fwd_fp8(const float* x, int64_t ldx, const float* g
 }
 
 namespace {
-// dgamma[c] += sum_r dy[r][c] * xhat[r][c], dbeta[c] += sum_r dy[r][c]: one thread per column walks the rows in order
-// (bitwise reproducible).  The path trains ln_post only (B*T rows), so the walk is short; beyond AIM_LN_DPARAM_ROWS rows the
+// dgamma[c] += sum_r dy[r][c] * xhat[r][c], dbeta[c] += sum_r dy[r][c] in a fixed order (bitwise reproducible).  The path trains ln_post only (B*T rows), so the walk is short; beyond AIM_LN_DPARAM_ROWS rows the
 // main kernel's per-element atomics are used instead.
+// (256 threads = 64 columns x 4 row groups, a thread walks rows g, g+4, ... with the loads of four rows in flight, the groups
+//  meet in LDS in a fixed order: the first version walked all rows in one thread, one dependent row at a time -- 146 us for
+//  512 rows of ln_post.)
 template <typename TDY>
-__global__ __launch_bounds__(64) void ln_dparam_kernel(const TDY* __restrict__ dy, long long lddy, const float* __restrict__ x,
-                                                      long long ldx, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta, int rows, int D) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= D) return;
+__global__ __launch_bounds__(256) void ln_dparam_kernel(const TDY* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                       long long ldx, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int rows, int D) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool live = c < D;
+    const int cc = live ? c : 0;
     float ag = 0.f, ab = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const float d = (float)dy[(long long)r * lddy + c];
-        ag += d * ((x[(long long)r * ldx + c] - mean[r]) * rstd[r]);
+    int r = g;
+    for (; r + 12 < rows; r += 16) {
+        float d[4], xv[4], mu[4], rs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + 4 * u;
+            d[u] = (float)dy[(long long)rr * lddy + cc];
+            xv[u] = x[(long long)rr * ldx + cc];
+            mu[u] = mean[rr];
+            rs[u] = rstd[rr];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ag += d[u] * ((xv[u] - mu[u]) * rs[u]);
+            ab += d[u];
+        }
+    }
+    for (; r < rows; r += 4) {
+        const float d = (float)dy[(long long)r * lddy + cc];
+        ag += d * ((x[(long long)r * ldx + cc] - mean[r]) * rstd[r]);
         ab += d;
     }
-    dgamma[c] += ag;
-    dbeta[c] += ab;
+    red[0][g][cl] = ag;
+    red[1][g][cl] = ab;
+    __syncthreads();
+    if (g == 0 && live) {
+        dgamma[c] += (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        dbeta[c] += (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
 }
 constexpr int AIM_LN_DPARAM_ROWS = 8192;
 }  // namespace
@@ -278,10 +305,10 @@ extern "C" int aim_layernorm_bwd(const void* dy, int dy_is_bf16, int64_t lddy, c
     AIM_CHECK_ARG((ldx % 4) == 0 && (lddy % 4) == 0 && (lddx % 4) == 0, "layernorm_bwd: strides must be multiples of 4");
     if (dgamma && rows <= AIM_LN_DPARAM_ROWS) {      // parameter gradients apart, in a fixed order
         if (dy_is_bf16)
-            hipLaunchKernelGGL(ln_dparam_kernel<bf16_t>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dy,
+            hipLaunchKernelGGL(ln_dparam_kernel<bf16_t>, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                                (long long)lddy, x, (long long)ldx, mean, rstd, dgamma, dbeta, rows, D);
         else
-            hipLaunchKernelGGL(ln_dparam_kernel<float>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)dy,
+            hipLaunchKernelGGL(ln_dparam_kernel<float>, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                                (long long)lddy, x, (long long)ldx, mean, rstd, dgamma, dbeta, rows, D);
         AIM_CHECK_LAUNCH("aim_layernorm_bwd(dparam)");
         dgamma = nullptr;
