@@ -59,6 +59,15 @@ def run(name, N, K, epi):
     print(f"{name:12s} N={N} K={K}: tiles {len(p)}  kernel span {total:7.1f} us | K-loop us mean {kl.mean():6.2f} "
           f"p10 {np.percentile(kl, 10):6.2f} p90 {np.percentile(kl, 90):6.2f} | epilogue us mean {ep.mean():6.2f} "
           f"p10 {np.percentile(ep, 10):6.2f} p90 {np.percentile(ep, 90):6.2f}", flush=True)
+    # by tile ordinal inside a workgroup: K-loop time of a workgroup's first tile (nothing in flight before it) vs later ones
+    order = np.lexsort((p[:, 1], p[:, 0]))
+    ps = p[order]
+    first = np.r_[True, ps[1:, 0] != ps[:-1, 0]]
+    ordn = np.arange(len(ps)) - np.maximum.accumulate(np.where(first, np.arange(len(ps)), 0))
+    klo = (ps[:, 2] - ps[:, 1]) * 0.01
+    gap = np.r_[0, (ps[1:, 1] - ps[:-1, 3]) * 0.01]
+    print("   K-loop us by tile ordinal:", " ".join(f"{o}:{klo[ordn == o].mean():.2f}" for o in range(min(6, ordn.max() + 1))),
+          "| start spread of ordinal 3 (p5..p95) us:", [round(float(x), 1) for x in np.percentile((ps[ordn == min(3, ordn.max()), 1] - t0) * 0.01, [5, 50, 95])])
     # first workgroup's timeline
     wg0 = p[p[:, 0] == 0]
     wg0 = wg0[np.argsort(wg0[:, 1])]
