@@ -328,7 +328,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
             read_b(0); read_a(0, 0);                               // ---- Ra
             stage(1, 0, to, to); stage(1, 1, to, to);
             if (!F8 && lastit) {    // this tile's last own stage is out: the staging state moves on to the next tile
-                const TileSrc t = make_tile<ES>(g, nxt_tile, ntiles, tiles_n, tiles_m1, wave, srow, schunk);
+                // (laundered lane: otherwise the tile-independent part of the eight row offsets is hoisted out of the tile loop,
+                //  eight more live VGPRs, and the F32 kernel reloads spilled ones here behind an s_waitcnt vmcnt(0))
+                int ll = lane;
+                asm volatile("" : "+v"(ll));
+                const TileSrc t = make_tile<ES>(g, nxt_tile, ntiles, tiles_n, tiles_m1, wave, ll >> 3, (ll & 7) ^ (ll >> 3));
                 cur.rA = t.rA;
                 cur.rW = t.rW;
                 cur.rX = t.rX;
