@@ -1040,15 +1040,23 @@ class ViT_CLIP(nn.Module):
         """Both DropPath factors of every block, ``[L, 2, N]`` (same distribution as ``_drop_mask`` per call; one
         uniform draw for the whole model instead of 2 L bernoulli launches)."""
         blocks = self.transformer.resblocks
-        rates = torch.tensor([b.drop_prob for b in blocks], dtype=F32)
-        scale = torch.tensor([float(b.scale) for b in blocks], dtype=F32)
         L = len(blocks)
-        if not training or float(rates.max()) <= 0.:
-            return scale.to(dev).view(L, 1, 1).expand(L, 2, N).contiguous()
-        keep = (1.0 - rates)
-        fac = torch.where(keep > 0, scale / keep.clamp_min(1e-12), torch.zeros_like(keep)).to(dev).view(L, 1, 1)
+        # the per-layer constants live on the device: building them on the host every step costs two pageable
+        # host-to-device copies, each of which stalls the host until the stream has drained (no run-ahead across steps)
+        key = (str(dev), tuple(float(b.drop_prob) for b in blocks), tuple(float(b.scale) for b in blocks))
+        cached = getattr(self, "_drop_consts", None)
+        if cached is None or cached[0] != key:
+            rates = torch.tensor(key[1], dtype=F32)
+            scale = torch.tensor(key[2], dtype=F32)
+            keep = 1.0 - rates
+            fac = torch.where(keep > 0, scale / keep.clamp_min(1e-12), torch.zeros_like(keep))
+            cached = (key, float(rates.max()), scale.to(dev).view(L, 1, 1), keep.to(dev).view(L, 1, 1), fac.to(dev).view(L, 1, 1))
+            self._drop_consts = cached
+        _, max_rate, scale_d, keep_d, fac_d = cached
+        if not training or max_rate <= 0.:
+            return scale_d.expand(L, 2, N).contiguous()
         u = torch.rand((L, 2, N), dtype=F32, device=dev)
-        return (u < keep.to(dev).view(L, 1, 1)).to(F32) * fac
+        return (u < keep_d).to(F32) * fac_d
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):

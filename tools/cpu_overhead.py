@@ -16,3 +16,12 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue time/step {1e3*(t1-t0)/5:.1f} ms ; wall/step {1e3*(t2-t0)/5:.1f} ms")
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5): step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)

@@ -37,6 +37,45 @@ def main():
     print("| kernel | calls/step | ms/step | avg us | % of kernel time |\n|---|---|---|---|---|")
     for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
         print(f"| `{n}` | {v[0] / steps:.1f} | {v[1] / steps:.3f} | {v[1] / v[0] * 1e3:.1f} | {100 * v[1] / tot:.2f} |")
+    if len(sys.argv) > 4 and sys.argv[4] == "main":
+        main_stream(rows, steps, short)
+
+
+def main_stream(rows, steps, short):
+    """Main stream only (the stream with the most busy time): kernel time by name, and the idle gaps between its kernels."""
+    import collections
+    busy = collections.defaultdict(float)
+    for st, a, b, n in rows:
+        busy[st] += b - a
+    ms = max(busy, key=busy.get)
+    r = [(a, b, short(n)) for st, a, b, n in rows if st == ms]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    gaps = collections.defaultdict(lambda: [0, 0.0])
+    for i, (a, b, n) in enumerate(r):
+        agg[n][0] += 1
+        agg[n][1] += (b - a) / 1e6
+        if i:
+            g = (a - r[i - 1][1]) / 1e6
+            if 0 < g < 5.0:          # (step boundaries with host work between them are longer)
+                gaps[n][0] += 1
+                gaps[n][1] += g
+    import os
+    if os.environ.get("AIM_PROF_DUMP"):      # raw timeline of the middle of the trace: start us, duration us, gap us, stream, name
+        allr = [(a, b, st, short(n)) for st, a, b, n in rows]
+        mid = len(allr) // 2
+        t0 = allr[mid][0]
+        with open(os.environ["AIM_PROF_DUMP"], "w") as f:
+            last_end = {}
+            for a, b, st, n in allr[mid:mid + 900]:
+                g = (a - last_end[st]) / 1e3 if st in last_end else 0.0
+                last_end[st] = b
+                f.write(f"{(a - t0) / 1e3:10.1f} {(b - a) / 1e3:8.1f} {g:8.1f} s{st} {n[:60]}\n")
+    print(f"\n## main stream ({ms}): kernel time and the idle gap before each kernel, ms/step\n")
+    print(f"kernels {sum(v[1] for v in agg.values()) / steps:.2f}, gaps {sum(v[1] for v in gaps.values()) / steps:.2f}\n")
+    print("| kernel | calls/step | ms/step | avg us | gap before, ms/step | avg gap us |\n|---|---|---|---|---|---|")
+    for n, v in sorted(agg.items(), key=lambda kv: -(kv[1][1] + gaps[kv[0]][1]))[:40]:
+        g = gaps[n]
+        print(f"| `{n}` | {v[0] / steps:.1f} | {v[1] / steps:.3f} | {v[1] / v[0] * 1e3:.1f} | {g[1] / steps:.3f} | {g[1] / max(g[0], 1) * 1e3:.1f} |")
 
 
 if __name__ == "__main__":
