@@ -323,6 +323,12 @@ struct PfPos {                                   // a tick's item: workgroup-loc
     int k, qb, bt, h;
 };
 
+// XT ("extra tile"): N = 64 j + r with 1 <= r <= 16 and j >= 2 (197 = 3 x 64 + 5).  The r left-over queries would cost a
+// whole tick of their own (barrier, loads, a 64-row chunk that is 92 % padding: 3.0 of an item's 15 us); instead they ride
+// with the item's LAST chunk as a fifth 16-query tile -- their Q / dO rows, L / delta and dS image live in small
+// single-buffered LDS areas beside the ring (written and read once per item, three ticks apart), the producers run one more
+// half step on them, and their dQ goes to waves 2 and 3.
+template <bool XT>
 __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int N, int H, int nkb, int items
@@ -346,6 +352,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
     AIM_LDS float* sLD = (AIM_LDS float*)(sRing + 2 * PF_SLOT); // 2 x {L[64], delta[64]}
     AIM_LDS char* sKimg = sRing + 2 * PF_SLOT + 1024;           // 2 x [nrow][128 B]: item k in buffer k & 1
     AIM_LDS char* sDS = sKimg + 2 * nrow * 128;                 // 2 x [key][64 queries] bf16
+    AIM_LDS char* sXQ = sDS + 2 * nrow * 128;                   // XT: Q [16][128 B] + dO [16][128 B] of the extra tile
+    AIM_LDS char* sXDS = sXQ + 4096;                            // XT: [key][16 queries] bf16, 32-byte rows
+    AIM_LDS float* sXLD = (AIM_LDS float*)(sXDS + nrow * 32);   // XT: L[16], -delta[16]
 
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -354,7 +363,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
     const bool producer = wave < nkb;
     const bool deltaw = wave == 7;                               // (nkb <= 7: wave 7 owns no keys)
-    const int nqb = (nrow + 63) >> 6;                            // ticks per item (>= 2: N >= 65)
+    const int nqb = XT ? N >> 6 : (nrow + 63) >> 6;              // ticks per item (>= 2: N >= 65; XT: N >= 129)
+    const int xq0 = nqb * 64;                                    // XT: first query of the extra tile
     const int nit = ((int)items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nt = nit * nqb;
     const int gbt = (int)gridDim.x / H, gh = (int)gridDim.x - gbt * H;      // item stride of the workgroup as (frames, heads)
@@ -384,11 +394,18 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
         const int r = p.qb * 64 + wave * 8 + srow;
         stage_piece_asm(rQ, slot + wave * 1024, r < N ? (unsigned)((r * ld + schunk * 8) * 2) : AIM_OOB);
         stage_piece_asm(rO, slot + 8192 + wave * 1024, r < N ? (unsigned)((r * D + schunk * 8) * 2) : AIM_OOB);
+        if (XT && p.qb == nqb - 1 && wave < 4) {      // the extra tile: waves 0, 1 its two Q pieces, waves 2, 3 the dO pieces
+            const int rx = xq0 + (wave & 1) * 8 + srow;
+            if (wave < 2) stage_piece_asm(rQ, sXQ + (wave & 1) * 1024, rx < N ? (unsigned)((rx * ld + schunk * 8) * 2) : AIM_OOB);
+            else stage_piece_asm(rO, sXQ + 2048 + (wave & 1) * 1024, rx < N ? (unsigned)((rx * D + schunk * 8) * 2) : AIM_OOB);
+        }
     };
     // delta = rowsum(dO o O) and L of a chunk, by the wave that owns no keys (wave 7), straight from global memory: 8 lanes
     // per query row, 8 rows per load, the operands parked in that wave's otherwise unused accumulator registers.  (With every
     // wave loading its own share, each paid ~0.5 us per tick for three loads, the shuffles and the address arithmetic.)
-    float lreg = 0.f;
+    float lreg = 0.f, lregx = 0.f;
+    bf16x8 vf[2][2] = {}, vfn[2][2] = {};          // producers: V fragments of the item / of the next one.  XT: wave 7 (no
+                                                   // keys) parks the extra tile's O / dO row parts in vfn[g][0] / vfn[g][1]
     auto issue_delta = [&](const PfPos& p) {
         const bf16_t* ob = out + ((long long)p.bt * N * D + p.h * 64);       // wave-uniform bases, 32-bit lane offsets
         const bf16_t* dob = dout + ((long long)p.bt * N * D + p.h * 64);
@@ -401,6 +418,17 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
         }
         const int ql = p.qb * 64 + lane;
         lreg = (lse + ((long long)p.bt * H + p.h) * N)[ql < N ? ql : N - 1];
+        if (XT && p.qb == nqb - 1) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int q = xq0 + g * 8 + srow;
+                const unsigned off = (unsigned)((q < N ? q : N - 1) * D + (lane & 7) * 8);
+                vfn[g][0] = *(const bf16x8*)(ob + off);
+                vfn[g][1] = *(const bf16x8*)(dob + off);
+            }
+            const int qx = xq0 + (lane & 15);
+            lregx = (lse + ((long long)p.bt * H + p.h) * N)[qx < N ? qx : N - 1];
+        }
     };
     auto finish_delta = [&](const PfPos& p, AIM_LDS float* sl) {
 #pragma unroll
@@ -418,6 +446,20 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
             if ((lane & 7) == 0) sl[64 + g * 8 + srow] = p.qb * 64 + g * 8 + srow < N ? -dl : 0.f;
         }
         sl[lane] = p.qb * 64 + lane < N ? lreg * LOG2E : 0.f;
+        if (XT && p.qb == nqb - 1) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const bf16x8 o8 = vfn[g][0], d8 = vfn[g][1];
+                float dl = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)d8[e] * (float)o8[e];
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0xB1, 0xF, 0xF, true));
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x4E, 0xF, 0xF, true));
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dl), 0x141, 0xF, 0xF, true));
+                if ((lane & 7) == 0) sXLD[16 + g * 8 + srow] = xq0 + g * 8 + srow < N ? -dl : 0.f;
+            }
+            if (lane < 16) sXLD[lane] = xq0 + lane < N ? lregx * LOG2E : 0.f;
+        }
     };
     auto issue_kimg = [&](const PfPos& p) {
         const bf16_t* base = qkv + (long long)p.bt * N * ld + p.h * 64;
@@ -428,7 +470,6 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
             stage_piece_asm(rK, img + pc * 1024, r < N ? (unsigned)((r * ld + schunk * 8) * 2) : AIM_OOB);
         }
     };
-    bf16x8 vf[2][2] = {}, vfn[2][2] = {};
     auto issue_v = [&](const PfPos& p) {        // producers: V row fragments of an item -> vfn
         const bf16_t* base = qkv + (long long)p.bt * N * ld + p.h * 64;
 #pragma unroll
@@ -456,6 +497,50 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                     *(bf16x8*)(op + 2 * D + dt * 16) = vv;
                 }
             }
+        }
+    };
+
+    // dQ tile pair += sum over the item's keys of dS^T K: fragments of 32 keys at a time by transposing reads.  The key loop
+    // is latency-bound (six dependent-free reads, two MFMAs, repeat: every wave spent ~1 us of a 3.7 us tick in it), so it
+    // runs THREE key blocks per trip: eighteen reads in flight, then six MFMAs.  ds_at(row) -> the lane's dS bytes in key row `row`.
+    auto dq_keys = [&](auto ds_at, const AIM_LDS char* sK, int chk0, int chk1, int half, int rl, f32x4& dq0, f32x4& dq1) {
+        auto step = [&](int kk, bf16x4 (&f)[6]) {
+            const int r0 = kk * 32 + rl;
+            f[0] = lds_read_tr4(ds_at(r0));
+            f[1] = lds_read_tr4(ds_at(r0 + 16));
+            f[2] = lds_read_tr4(sK + swz_off(r0, chk0) + half);
+            f[3] = lds_read_tr4(sK + swz_off(r0 + 16, chk0) + half);
+            f[4] = lds_read_tr4(sK + swz_off(r0, chk1) + half);
+            f[5] = lds_read_tr4(sK + swz_off(r0 + 16, chk1) + half);
+        };
+        auto mul = [&](const bf16x4 (&f)[6]) {
+            bf16x8 dsT, kt0, kt1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dsT[e] = f[0][e];
+                dsT[4 + e] = f[1][e];
+                kt0[e] = f[2][e];
+                kt0[4 + e] = f[3][e];
+                kt1[e] = f[4][e];
+                kt1[4 + e] = f[5][e];
+            }
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsT, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsT, dq1, 0, 0, 0);
+        };
+        int kk = 0;
+        for (; kk + 3 <= nkb; kk += 3) {
+            bf16x4 fa[6], fb[6], fc[6];
+            step(kk, fa);
+            step(kk + 1, fb);
+            step(kk + 2, fc);
+            mul(fa);
+            mul(fb);
+            mul(fc);
+        }
+        for (; kk < nkb; ++kk) {
+            bf16x4 fa[6];
+            step(kk, fa);
+            mul(fa);
         }
     };
 
@@ -538,29 +623,27 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                 f32x4 dq0 = f32x4{0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
                 const int chq = qt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
                 const int chk0 = dt0 * 2 + ((frow & 3) >> 1), chk1 = chk0 + 2;
-                for (int kk = 0; kk < nkb; ++kk) {
-                    const int r0 = kk * 32 + fq * 4 + (frow >> 2);
-                    const bf16x4 sa = lds_read_tr4(ds_img + swz_off(r0, chq) + half);
-                    const bf16x4 sb = lds_read_tr4(ds_img + swz_off(r0 + 16, chq) + half);
-                    const bf16x4 ka = lds_read_tr4(sK + swz_off(r0, chk0) + half);
-                    const bf16x4 kb = lds_read_tr4(sK + swz_off(r0 + 16, chk0) + half);
-                    const bf16x4 kc = lds_read_tr4(sK + swz_off(r0, chk1) + half);
-                    const bf16x4 kd = lds_read_tr4(sK + swz_off(r0 + 16, chk1) + half);
-                    bf16x8 dsT, kt0, kt1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dsT[e] = sa[e];
-                        dsT[4 + e] = sb[e];
-                        kt0[e] = ka[e];
-                        kt0[4 + e] = kb[e];
-                        kt1[e] = kc[e];
-                        kt1[4 + e] = kd[e];
-                    }
-                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsT, dq0, 0, 0, 0);
-                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsT, dq1, 0, 0, 0);
-                }
+                dq_keys([&](int r) { return ds_img + swz_off(r, chq) + half; }, sK, chk0, chk1, half, fq * 4 + (frow >> 2), dq0, dq1);
                 // lane holds dQ[q][d = 16 dt + 4 fq + e]; tiles (dt0, dt0+1) paired across even / odd 16-lane rows: 16-byte stores
                 const int q = prv.qb * 64 + qt * 16 + frow;
+                bf16_t* op = dqkv + ((long long)prv.bt * N + (q < N ? q : 0)) * ld + prv.h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
+                const f32x4 a = dq0 * 0.125f, b = dq1 * 0.125f;
+                const bf16x8 v = pair_rows16(pack4(a[0], a[1], a[2], a[3]), pack4(b[0], b[1], b[2], b[3]));
+                if (q < N) *(bf16x8*)(op + dt0 * 16) = v;
+            }
+            if (XT && prv.qb == nqb - 1 && (wave >> 1) == 1) {
+                // dQ of the extra tile of chunk T-1: waves 2 and 3, two d tiles each.  (Not wave 7: at an item's first tick its
+                // delta work queues behind the producers' dK / dV stores and it is the tick's critical path already.)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int frow = ln & 15, fq = ln >> 4;
+                const int dt0 = (wave & 1) * 2;
+                const AIM_LDS char* sK = sKimg + (prv.k & 1) * nrow * 128;
+                f32x4 dq0 = f32x4{0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+                const int xoff = ((frow & 3) >> 1) * 16 + (frow & 1) * 8, half = (frow & 1) * 8;
+                const int chk0 = dt0 * 2 + ((frow & 3) >> 1), chk1 = chk0 + 2;
+                dq_keys([&](int r) { return sXDS + r * 32 + xoff; }, sK, chk0, chk1, half, fq * 4 + (frow >> 2), dq0, dq1);
+                const int q = xq0 + frow;
                 bf16_t* op = dqkv + ((long long)prv.bt * N + (q < N ? q : 0)) * ld + prv.h * 64 + ((fq & 1) ? 16 + (fq - 1) * 4 : fq * 4);
                 const f32x4 a = dq0 * 0.125f, b = dq1 * 0.125f;
                 const bf16x8 v = pair_rows16(pack4(a[0], a[1], a[2], a[3]), pack4(b[0], b[1], b[2], b[3]));
@@ -649,6 +732,61 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                     }
                 }
             }
+            if (XT && cur.qb == nqb - 1) {
+                // the extra tile: one 16-query half step (the upper 16 k-positions of the dV / dK products are zero)
+                const AIM_LDS char* xQ = sXQ;
+                const AIM_LDS char* xO = sXQ + 2048;
+                bf16x4 ta[4], tc[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int r0 = fq * 4 + (frow >> 2);
+                    const int ch = dt * 2 + ((frow & 3) >> 1), half = (frow & 1) * 8;
+                    ta[dt] = lds_read_tr4(xQ + swz_off(r0, ch) + half);
+                    tc[dt] = lds_read_tr4(xO + swz_off(r0, ch) + half);
+                }
+                bf16x8 pf[2] = {}, dsf[2] = {};
+                bf16x8 qa[2], oa[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    qa[ks] = lds_read8(xQ + swz_off(frow, ks * 4 + fq));
+                    oa[ks] = lds_read8(xO + swz_off(frow, ks * 4 + fq));
+                }
+                const f32x4 Lr = *(const AIM_LDS f32x4*)(sXLD + fq * 4);
+                const f32x4 Dr = *(const AIM_LDS f32x4*)(sXLD + 16 + fq * 4);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = Dr;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[u][ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[ks], vf[u][ks], dp, 0, 0, 0);
+                    }
+                    bf16x4 ds4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(s[e] * C2 - Lr[e]);
+                        pf[u][e] = (bf16_t)p;
+                        const bf16_t d = (bf16_t)(p * dp[e]);
+                        dsf[u][e] = d;
+                        ds4[e] = d;
+                    }
+                    *(AIM_LDS bf16x4*)(sXDS + (wave * 32 + u * 16 + frow) * 32 + fq * 8) = ds4;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x8 qt8 = {}, ot8 = {};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        qt8[e] = ta[dt][e];
+                        ot8[e] = tc[dt][e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        acc[8 + dt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot8, pf[u], acc[8 + dt * 2 + u], 0, 0, 0);
+                        acc[dt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsf[u], acc[dt * 2 + u], 0, 0, 0);
+                    }
+                }
+            }
         }
         PST(4);
         prv = cur;
@@ -685,10 +823,13 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
     if (pipe_on && N <= 224 && N >= 65) {
         const int nkb = (N + 31) / 32;
         const int nrow = nkb * 32;
-        const int lds = 2 * PF_SLOT + 4 * nrow * 128 + 2 * 128 * 4;
+        static const bool xt_on = [] { const char* e = getenv("AIM_ATTN_PIPE_XT"); return !e || atoi(e) != 0; }();
+        const bool xt = xt_on && N >= 129 && ((N - 1) & 63) < 16;        // 64 j + 1 .. 64 j + 16, j >= 2
+        const int lds = 2 * PF_SLOT + 4 * nrow * 128 + 2 * 128 * 4 + (xt ? 4096 + nrow * 32 + 128 : 0);
         static bool attr_set2 = false;
         if (!attr_set2) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set2 = true;
         }
         const int items = BT * H;
@@ -705,12 +846,20 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
         static const int grid_cap = [] { const char* e = getenv("AIM_ATTN_PIPE_GRID"); return e ? atoi(e) : 0; }();   // tests: few workgroups, many items each
         if (grid_cap > 0 && grid_cap < cus) cus = grid_cap;
         const int grid = items < cus ? items : cus;
-        hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(grid), dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                           (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nkb, items
+        if (xt)
+            hipLaunchKernelGGL(attn_bwd_pipe_kernel<true>, dim3(grid), dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                               (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nkb, items
 #ifdef AIM_X_STAMPS
-                           , (unsigned long long*)delta
+                               , (unsigned long long*)delta
 #endif
-        );
+            );
+        else
+            hipLaunchKernelGGL(attn_bwd_pipe_kernel<false>, dim3(grid), dim3(512), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                               (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nkb, items
+#ifdef AIM_X_STAMPS
+                               , (unsigned long long*)delta
+#endif
+            );
         AIM_CHECK_LAUNCH("aim_attn_bwd(pipelined)");
         return 0;
     }

@@ -267,12 +267,24 @@ def test_attn_bwd_two_kernel_form(BT, N, H, monkeypatch):
     assert float(delta.abs().max()) > 0.0           # this form writes delta = rowsum(dO o O) to the scratch
 
 
-@pytest.mark.parametrize("BT,N,H,grid", [(3, 197, 12, 5), (2, 65, 1, 1), (2, 224, 2, 3), (5, 130, 3, 4), (4, 96, 2, 8), (30, 197, 12, 0)])
+@pytest.mark.parametrize("BT,N,H,grid", [(3, 197, 12, 5), (2, 65, 1, 1), (2, 224, 2, 3), (5, 130, 3, 4), (4, 96, 2, 8), (30, 197, 12, 0),
+                                         (3, 129, 2, 2), (2, 144, 1, 1), (3, 193, 1, 2), (2, 208, 2, 3), (2, 145, 1, 1), (2, 209, 2, 2)])
 def test_attn_bwd_pipelined(BT, N, H, grid, monkeypatch):
     """The pipelined fused backward (the default for 65 <= N <= 224: persistent workgroups, loads one to two query blocks
     ahead across (frame, head) items) against plain PyTorch autograd.  AIM_ATTN_PIPE_GRID caps the grid so that a workgroup
     walks several items (item switches, K-image double buffer, deferred dK / dV stores) even at test sizes; run twice for
-    bit-equality."""
+    bit-equality.  N = 64 j + 1 .. 64 j + 16 (j >= 2: 129..144, 193..208, so 197) takes the extra-tile form of the kernel."""
+    _pipelined_case(BT, N, H, grid, monkeypatch)
+
+
+@pytest.mark.parametrize("BT,N,H,grid", [(3, 197, 12, 5), (5, 130, 3, 4)])
+def test_attn_bwd_pipelined_without_extra_tile(BT, N, H, grid, monkeypatch):
+    """The same shapes with AIM_ATTN_PIPE_XT=0: the left-over queries get a tick of their own (the general form)."""
+    monkeypatch.setenv("AIM_ATTN_PIPE_XT", "0")
+    _pipelined_case(BT, N, H, grid, monkeypatch)
+
+
+def _pipelined_case(BT, N, H, grid, monkeypatch):
     import ctypes, shutil, tempfile, os
     from aim_amd import lib as L
     ops = _ops()
