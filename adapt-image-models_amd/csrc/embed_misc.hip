@@ -31,17 +31,51 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ i
     const int t = (int)(bt % T);
     const long long b = bt / T;
     bf16x8 o;
+    if ((p & 7) == 0 && (W & 7) == 0 && k0 + 8 <= K && ((unsigned long long)img & 15) == 0) {
+        // patch width a multiple of 8 (ViT-B/16): the thread's 8 columns are 8 consecutive pixels of one image row -> one or
+        // two 16-byte loads instead of eight scalar ones with their index arithmetic
+        const int c = k0 / (p * p), rem = k0 - c * p * p, py = rem / p, px = rem - py * p;
+        const TIN* src = img + (((b * 3 + c) * T + t) * H + (gy * p + py)) * (long long)W + gx * p + px;
+        float v[8];
+        if constexpr (sizeof(TIN) == 4) {
+            const f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = k0 + e;
-        float v = 0.f;
-        if (k < K) {
-            const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
-            const long long src = (((b * 3 + c) * T + t) * H + (gy * p + py)) * (long long)W + gx * p + px;
-            v = (float)img[src];
-            if (mean3) v = (v - mean3[c]) / std3[c];
+            for (int e = 0; e < 4; ++e) {
+                v[e] = a0[e];
+                v[4 + e] = a1[e];
+            }
+        } else if constexpr (sizeof(TIN) == 2) {
+            const bf16x8 a0 = *(const bf16x8*)src;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)a0[e];
+        } else {
+            const uint2 a0 = *(const uint2*)src;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (float)((a0.x >> (8 * e)) & 0xffu);
+                v[4 + e] = (float)((a0.y >> (8 * e)) & 0xffu);
+            }
         }
-        o[e] = (bf16_t)v;
+        if (mean3) {
+            const float m = mean3[c], sd = std3[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - m) / sd;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
+                const long long src = (((b * 3 + c) * T + t) * H + (gy * p + py)) * (long long)W + gx * p + px;
+                v = (float)img[src];
+                if (mean3) v = (v - mean3[c]) / std3[c];
+            }
+            o[e] = (bf16_t)v;
+        }
     }
     *(bf16x8*)(A + row * Kp + k0) = o;
 }
@@ -415,13 +449,48 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const aim_cast_desc* __
     const aim_cast_desc d = table[blockIdx.x];
     const float* src = (const float*)d.src;
     bf16_t* dst = (bf16_t*)d.dst;
-    const long long n = (long long)d.R * d.C;
-    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long long)gridDim.y * 256) {
-        const int r = (int)(i / d.C), c = (int)(i - (long long)r * d.C);
+    const int n = d.R * d.C;                        // (ops.CastTable checks R * C < 2^31)
+    if (d.transpose == 0 && (d.C & 3) == 0 && (d.ldd & 3) == 0 && ((unsigned long long)src & 15) == 0 && ((unsigned long long)dst & 7) == 0) {
+        // row-major cast, four elements per thread
+        const int n4 = n >> 2, c4n = d.C >> 2;
+        for (int i = (int)blockIdx.y * 256 + threadIdx.x; i < n4; i += (int)gridDim.y * 256) {
+            const int r = i / c4n, c = (i - r * c4n) * 4;
+            const f32x4 v = *(const f32x4*)(src + (long long)i * 4);
+            *(bf16x4*)(dst + (long long)r * d.ldd + c) = pack4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
+    if (d.transpose == 1 && (d.R & 31) == 0 && (d.C & 31) == 0) {
+        // transposed cast by 32 x 32 tiles through LDS: coalesced reads along C, coalesced writes along R
+        __shared__ float tile[32][33];
+        const int tc = d.C >> 5, ntile = (d.R >> 5) * tc;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 8 rows of 32 per pass
+        for (int tl = blockIdx.y; tl < ntile; tl += gridDim.y) {
+            const int r0 = (tl / tc) * 32, c0 = (tl - (tl / tc) * tc) * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[ty + k * 8][tx] = src[(long long)(r0 + ty + k * 8) * d.C + c0 + tx];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[(long long)(c0 + ty + k * 8) * d.ldd + r0 + tx] = (bf16_t)tile[tx][ty + k * 8];
+            __syncthreads();
+        }
+        return;
+    }
+    // (r, c) advance incrementally: no division per element
+    const int step = (int)gridDim.y * 256, dr = step / d.C, dc = step - dr * d.C;
+    int i = (int)blockIdx.y * 256 + threadIdx.x;
+    int r = i / d.C, c = i - r * d.C;
+    for (; i < n; i += step) {
         const float v = src[i];
         if (d.transpose == 2) ((float*)d.dst)[(long long)r * d.ldd + c] = v;       // fp32 copy (bias staging)
         else if (d.transpose) dst[(long long)c * d.ldd + r] = (bf16_t)v;
         else dst[(long long)r * d.ldd + c] = (bf16_t)v;
+        r += dr;
+        c += dc;
+        if (c >= d.C) {
+            c -= d.C;
+            ++r;
+        }
     }
 }
 

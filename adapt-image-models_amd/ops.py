@@ -458,7 +458,7 @@ class CastTable:
                                    int(tr)) for src, dst, tr in entries)
         for src, dst, tr in entries:       # tr: False / True = bf16 cast (plain / transposed); 2 = fp32 copy
             _chk(src, F32, "src"); _chk(dst, F32 if tr == 2 else BF16, "dst")
-            assert src.dim() == 2 and src.is_contiguous()
+            assert src.dim() == 2 and src.is_contiguous() and src.numel() < 2 ** 31
             assert tuple(dst.shape) == ((src.shape[1], src.shape[0]) if tr is True or tr == 1 else tuple(src.shape))
         self.n = len(entries)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
