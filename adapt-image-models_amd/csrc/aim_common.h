@@ -7,6 +7,15 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// Row-streaming kernels (LayerNorm, attention) walk their rows in DESCENDING order: workgroups are dispatched in ascending
+// blockIdx order, the GEMMs before and after them walk their tiles in ascending row order, and a consumer that starts with
+// the rows its producer wrote LAST finds more of them still in the memory-side cache (tools/mall_probe.py: ln_fwd over a
+// just-written 310 MB tensor 92 -> 84 us).  -DAIM_X_FWDROWS restores the ascending walk (A/B builds only).
+#ifdef AIM_X_FWDROWS
+#define AIM_REV_BLOCK (blockIdx.x)
+#else
+#define AIM_REV_BLOCK (gridDim.x - 1 - blockIdx.x)
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 

@@ -373,12 +373,21 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
         if (++p.qb == nqb) {
             p.qb = 0;
             ++p.k;
+#ifdef AIM_X_FWDROWS
             p.bt += gbt;
             p.h += gh;
             if (p.h >= H) {
                 p.h -= H;
                 ++p.bt;
             }
+#else
+            p.bt -= gbt;        // the items are walked from the LAST (frame, head) down (aim_common.h, AIM_REV_BLOCK)
+            p.h -= gh;
+            if (p.h < 0) {
+                p.h += H;
+                --p.bt;
+            }
+#endif
         }
     };
     f32x4 acc[16];                     // producers: dK / dV of their 32 keys
@@ -548,8 +557,13 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
     PfPos prv{0, 0, 0, 0}, cur, nx1, nx2;
     cur.k = 0;
     cur.qb = 0;
-    cur.bt = (int)blockIdx.x / H;
-    cur.h = (int)blockIdx.x - cur.bt * H;
+#ifdef AIM_X_FWDROWS
+    const int first = (int)blockIdx.x;
+#else
+    const int first = items - 1 - (int)blockIdx.x;
+#endif
+    cur.bt = first / H;
+    cur.h = first - cur.bt * H;
     nx1 = cur;
     advance(nx1);
     nx2 = nx1;

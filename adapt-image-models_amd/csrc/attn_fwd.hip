@@ -17,7 +17,7 @@
 #ifdef AIM_X_STAMPS      // diagnostic build only (tools/probe_attn.py): shader-clock stamps of one workgroup's waves
 static unsigned long long* g_attn_probe = nullptr;
 extern "C" int aim_attn_probe(void* buf) { g_attn_probe = (unsigned long long*)buf; return 0; }
-#define ATT_STAMP(i) do { if (probe && blockIdx.x == 3000) { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define ATT_STAMP(i) do { if (probe && bid == 3000) { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define ATT_STAMP(i)
 #endif
@@ -40,12 +40,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) stamps[i] = 0;
 #endif
+    const int bid = (int)AIM_REV_BLOCK;
     ATT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
     AIM_LDS char* sV = sK + NKT * 16 * 128;
 
-    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int bt = bid / H, h = bid - bt * H;
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16_t* __restri
     }
 #ifdef AIM_X_STAMPS
     stamps[15] = __builtin_amdgcn_s_memtime();
-    if (probe && blockIdx.x == 3000 && lane == 0) {
+    if (probe && bid == 3000 && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) probe[wave * 16 + i] = stamps[i];
     }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int D, float eps, unsigned char* __restrict__ y8 = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (int)AIM_REV_BLOCK * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 2;
     const float* xr = x + (long long)row * ldx;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows, int D) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (int)AIM_REV_BLOCK * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 2;
     const float mu = mean[row], rs = rstd[row];
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, (NC <= 4 ? 6 : 2)) void ln_bwd_fsum_kernel(con
     __shared__ f32x4 red[4][NC * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform rows: scalar address arithmetic
-    const int frame = blockIdx.x / G, g = blockIdx.x - frame * G;
+    const int bid = (int)AIM_REV_BLOCK;
+    const int frame = bid / G, g = bid - frame * G;
     const int rg = (ntok + G - 1) / G;
     const int n_end = min(ntok, (g + 1) * rg);
     const int nch = D >> 2;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, (NC <= 4 ? 6 : 2)) void ln_bwd_fsum_kernel(con
     for (int c = 0; c < NC; ++c) red[wave][lane + c * 64] = fs[c];
     __syncthreads();
     for (int ch = threadIdx.x; ch < nch; ch += 256)
-        *(f32x4*)(partial + (long long)blockIdx.x * D + ch * 4) = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
+        *(f32x4*)(partial + (long long)bid * D + ch * 4) = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
 }
 
 }  // namespace
