@@ -199,6 +199,15 @@ def test_droppath_mask_semantics():
         assert abs((mk[l] > 0).float().mean().item() - keep) < 0.03
         assert not torch.equal(mk[l, 0], mk[l, 1])
     assert torch.equal(model._drop_masks(7, False, torch.device(DEV)), torch.full((4, 2, 7), 0.5, device=DEV))
+    # the per-layer constants are cached on the device (no host-to-device copy per step) and follow the blocks' attributes
+    consts = model._drop_consts
+    mk2 = model._drop_masks(4000, True, torch.device(DEV))
+    assert model._drop_consts is consts and not torch.equal(mk, mk2)          # same constants, a new draw
+    model.transformer.resblocks[3].drop_prob = 0.5
+    mk3 = model._drop_masks(4000, True, torch.device(DEV))
+    assert model._drop_consts is not consts
+    vals = sorted(mk3[3].unique().cpu().tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 0.5 / 0.5) < 1e-6
 
 
 def test_full_size_properties():

@@ -446,6 +446,16 @@ def test_patchify_and_embed(p, res):
     nrm = (u8.float() - mean3.view(1, 3, 1, 1, 1)) / std3.view(1, 3, 1, 1, 1)
     ref = nrm.permute(0, 2, 1, 3, 4).reshape(B * T, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T * G * G, K)
     close(A[:, :K], ref, 1e-6, 2 ** -8, "patchify uint8+normalize")
+    # bf16 input, and an input whose base address is not 16-byte aligned (the 16-byte-load path must not be taken)
+    ib = imgs.to(torch.bfloat16)
+    ops.patchify(ib, A, B, T, res, res, p, Kp)
+    refb = ib.float().permute(0, 2, 1, 3, 4).reshape(B * T, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T * G * G, K)
+    close(A[:, :K], refb, 1e-6, 2 ** -8, "patchify bf16 input")
+    flat = torch.zeros(imgs.numel() + 1, device=DEV)
+    flat[1:] = imgs.reshape(-1)
+    ops.patchify(flat[1:].view_as(imgs), A, B, T, res, res, p, Kp)
+    ref = imgs.permute(0, 2, 1, 3, 4).reshape(B * T, 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T * G * G, K)
+    close(A[:, :K], ref, 1e-6, 2 ** -8, "patchify misaligned base")
     # embed + ln_pre, and its backward into temporal_embedding
     tok = rnd((B * T * G * G, D), 62, 1.0, torch.bfloat16)
     cls, pos = rnd((D,), 63), rnd((N, D), 64)
@@ -464,6 +474,35 @@ def test_patchify_and_embed(p, res):
     ops.embed_bwd(dx, tok, cls, pos, tmp.detach(), gamma, mean, rstd, dtmp, B, T, N, D)
     close(dtmp, tmp.grad, 2e-4, 1e-4, "embed_bwd dtemporal")
 
+
+
+def test_cast_table():
+    """aim_cast_multi: row casts (4-wide path and the scalar one), 32x32-tile transposes (and the scalar one), fp32 bias copies
+    into strided destinations, all in one launch."""
+    ops = _ops()
+    ents = []
+    exp = []
+    for i, (R, C, tr) in enumerate([(768, 192, False), (768, 192, True), (192, 768, True), (100, 36, True), (100, 36, False),
+                                    (33, 7, False), (1, 192, 2), (1, 3264, 2)]):
+        src = rnd((R, C), 200 + i)
+        if tr == 2:
+            big = torch.full((R, C + 64), float("nan"), device=DEV)
+            dst = big[:, 32:32 + C]
+            exp.append((dst, src.clone()))
+        elif tr:
+            big = torch.full((C, R + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+            dst = big[:, :R]
+            exp.append((dst, src.t().to(torch.bfloat16)))
+        else:
+            big = torch.full((R, C + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+            dst = big[:, :C]
+            exp.append((dst, src.to(torch.bfloat16)))
+        ents.append((src, dst, tr))
+    tab = ops.CastTable(ents, DEV)
+    tab.run()
+    torch.cuda.synchronize()
+    for k, (got, want) in enumerate(exp):
+        assert torch.equal(got, want), f"cast table entry {k}"
 
 def test_misc_reductions_and_casts():
     ops = _ops()
