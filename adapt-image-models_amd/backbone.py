@@ -251,6 +251,11 @@ _DETACH_WGRAD = os.environ.get("AIM_DETACH_WGRAD", "1") != "0"
 _DETACH_BIG = os.environ.get("AIM_DETACH_BIG", "1") != "0"
 _EXPSUM_DETACHED = os.environ.get("AIM_EXPSUM_DETACHED", "0") != "0"      # measured: -0.7 % (the GEMM doubles beside the attention)
 _DETACHED_PRIORITY = int(os.environ.get("AIM_DETACHED_PRIORITY", "0"))   # HIP stream priority of the weight-gradient stream
+# The buffers the activations' backward reads (`hcat_pre`, the adapters' `pre`) hold the activation's DERIVATIVE at the
+# pre-activation, written by the forward epilogue, instead of the pre-activation itself (aim_gemm_args.aux_grad): the dgrad
+# epilogues lose their exp / rcp.  AIM_AUX_GRAD=0 restores the pre-activation form (A/B runs).
+_AUX_GRAD = os.environ.get("AIM_AUX_GRAD", "1") != "0"
+_AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0"       # ... and the MLP's in the GEMM pair's own fragment order (aux_frag)
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
 
@@ -424,7 +429,7 @@ class _Fork:
 def _adapter_fwd_small(x_bf, ad: _AdapterW, rows, r, D, ar: _Arena, out_f32: bool):
     """Adapter on a few rows (class-token / per-frame vectors): D_fc1 -> GELU(erf) -> D_fc2."""
     pre, h = ar.take((rows, r), BF16), ar.take((rows, r), BF16)
-    ops.gemm(x_bf, ad.W1, ops.EPI_ACT, h, bias=ad.b1, out2=pre, act=ops.ACT_GELU)
+    ops.gemm(x_bf, ad.W1, ops.EPI_ACT, h, bias=ad.b1, out2=pre, act=ops.ACT_GELU, aux_grad=_AUX_GRAD)
     out = ar.take((rows, D), F32 if out_f32 else BF16)
     ops.gemm(h, ad.W2, ops.EPI_F32 if out_f32 else ops.EPI_BF16, out, bias=ad.b2)
     return out, pre, h
@@ -580,10 +585,14 @@ def _mlp_adapter_forward(x1, fz: _Frozen, dms2, N, save: bool):
     ops.layernorm_fwd(x1, fz.g2, fz.b2, M, D, D, y_bf16=xn, mean=mean2, rstd=rstd2)
     # the pre-activation is only needed by a backward: a no-grad forward passes no `out2` (the epilogue's stores to an empty
     # buffer resource are dropped: 658 MB per ViT-B block less to write)
-    hcat_pre = _empty((M, H4 + r), BF16, dev) if (save or M < 1024) else None     # (the small-M kernel always stores it)
+    frag = _AUX_FRAG and M >= 1024          # the large-tile kernel pair keeps it in its own fragment order (no re-tiling)
+    if frag:
+        hcat_pre = ops.frag_buffer(M, H4 + r, dev) if save else None
+    else:
+        hcat_pre = _empty((M, H4 + r), BF16, dev) if (save or M < 1024) else None     # (the small-M kernel always stores it)
     hcat = _empty((M, H4 + r), BF16, dev)
     ops.gemm(xn, fz.Wcat1, ops.EPI_ACT, hcat, bias=fz.bcat1, out2=hcat_pre, act=ops.ACT_QGELU, n_split=H4,
-             act2=ops.ACT_GELU, at=dms2, ntok=N)
+             act2=ops.ACT_GELU, at=dms2, ntok=N, aux_grad=_AUX_GRAD, aux_frag=frag and hcat_pre is not None)
     x2 = _empty((M, D), F32, dev)
     ops.gemm(hcat, fz.Wcat2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
     # the adapter's activation slice stays a VIEW of hcat (wgrad takes a row stride): no copy kernel in the forward, at the
@@ -607,7 +616,7 @@ def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: 
         ops.wgrad(dyb, a_s, gm["D_fc2.weight"], gm["D_fc2.bias"], at=dms2, ntok=N)
     dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
     ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=hcat_pre, act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
-             at=dms2, ntok=N)
+             at=dms2, ntok=N, aux_grad=_AUX_GRAD, aux_frag=_AUX_FRAG and dyb.shape[0] >= 1024)
     if _DETACH_BIG:
         big_later.append(lambda: ops.wgrad(dcat[:, H4:], xn, gm["D_fc1.weight"], gm["D_fc1.bias"]))
     else:
@@ -627,7 +636,7 @@ def _adapter_bwd_small(dout_bf, ad: _AdapterW, a_in, pre, h, grads, rows, r, D, 
     path: the two wgrad calls are appended to ``later`` (run by the caller off the critical stream)."""
     later.append(lambda: ops.wgrad(dout_bf, h, grads["D_fc2.weight"], grads["D_fc2.bias"]))
     dpre = ar.take((rows, r), BF16)
-    ops.gemm(dout_bf, ad.W2T, ops.EPI_DACT, dpre, aux=pre, act=ops.ACT_GELU)
+    ops.gemm(dout_bf, ad.W2T, ops.EPI_DACT, dpre, aux=pre, act=ops.ACT_GELU, aux_grad=_AUX_GRAD)
     later.append(lambda: ops.wgrad(dpre, a_in, grads["D_fc1.weight"], grads["D_fc1.bias"]))
     din = ar.take((rows, D), BF16 if need_dx_bf16 else F32)
     ops.gemm(dpre, ad.W1T, ops.EPI_BF16 if need_dx_bf16 else ops.EPI_F32, din)

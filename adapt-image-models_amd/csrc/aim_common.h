@@ -101,6 +101,18 @@ __device__ __forceinline__ f32x2 quick_gelu_grad2(f32x2 x) {
     const f32x2 s = sigmoid_1702_2(x);
     return s * (1.0f + (1.702f * x) * (1.0f - s));
 }
+// activation and derivative from ONE sigmoid (aim_gemm_args.aux_grad: the forward epilogue stores the derivative instead of the
+// pre-activation, so the dgrad epilogue is a multiply): d = s + 1.702 (y - y s) with y = x s
+__device__ __forceinline__ void quick_gelu_both2(f32x2 x, f32x2& y, f32x2& d) {
+    const f32x2 s = sigmoid_1702_2(x);
+    y = x * s;
+    d = s + 1.702f * (y - y * s);
+}
+__device__ __forceinline__ void quick_gelu_both(float x, float& y, float& d) {
+    const float s = sigmoid_1702(x);
+    y = x * s;
+    d = s + 1.702f * (y - y * s);
+}
 // erf GELU (nn.GELU(), reference vit_clip.py:52) and its derivative.  The normal CDF comes from Abramowitz & Stegun 7.1.26
 // (|error of erf| <= 1.5e-7, five FMAs + one rcp + one exp2) instead of libdevice's erff (~70 instructions with both of its
 // branches executed): the adapter's column tile of the fused c_fc GEMM spent 18 us (forward) / 24 us (backward) in its
@@ -116,6 +128,12 @@ __device__ __forceinline__ float gelu_cdf_gauss(float x, float& gauss) {
     P = __builtin_fmaf(t, P, 0.254829592f);
     P = P * t * gauss;                                                              // 1 - erf(|y|)
     return 0.5f * (y < 0.f ? P : 2.0f - P);
+}
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& d) {
+    float g;
+    const float c = gelu_cdf_gauss(x, g);
+    y = x * c;
+    d = __builtin_fmaf(x * 0.3989422804014327f, g, c);
 }
 #ifdef AIM_X_ERFF      // A/B builds only: libdevice erff
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

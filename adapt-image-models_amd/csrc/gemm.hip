@@ -195,12 +195,15 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
                          (epi == EPI_F32 ? ((g.ldr % 4) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128))
                                          : ((g.ldo % 8) == 0 && (epi != EPI_ACT || (g.ldo2 % 8) == 0) &&
                                             (epi != EPI_DACT || (g.ldaux % 8) == 0)));
-    if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64 && wide_ok)
+    if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64 && wide_ok) {
+        AIM_CHECK_ARG(!g.aux_frag || epi == EPI_ACT || epi == EPI_DACT, "gemm: aux_frag is an ACT / DACT option");
         return aim_gemm256_launch(g, epi, 1, st);
+    }
     if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N) && (g.K % 64) == 0) {
         AIM_CHECK_ARG(!g.xrow || (g.N < 256 && (g.ldx % 8) == 0), "gemm: EXPSUM extra key needs N < 256 and ldx %% 8 == 0");
         return aim_gemm256_launch(g, epi, batch, st);
     }
+    AIM_CHECK_ARG(!g.aux_frag, "gemm: aux_frag needs the large-tile kernel (ACT / DACT, batch 1, M >= 1024, N %% 8 == 0, K %% 64 == 0)");
     AIM_CHECK_ARG(!g.xrow, "gemm: `xrow` is only supported by the one-tile-per-item EXPSUM path");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(g, batch, st);

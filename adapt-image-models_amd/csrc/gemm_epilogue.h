@@ -60,18 +60,21 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, in
         *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_ACT) {
         const bf16x4 pre = pack4(v[0], v[1], v[2], v[3]);
-        *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
-        const float p0 = (float)pre[0], p1 = (float)pre[1], p2 = (float)pre[2], p3 = (float)pre[3];
-        const bf16x4 post = (act == ACT_QGELU)
-                                ? pack4(rs * quick_gelu(p0), rs * quick_gelu(p1), rs * quick_gelu(p2), rs * quick_gelu(p3))
-                                : pack4(rs * gelu_erf(p0), rs * gelu_erf(p1), rs * gelu_erf(p2), rs * gelu_erf(p3));
-        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = post;
+        float y[4], d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (act == ACT_QGELU) quick_gelu_both((float)pre[e], y[e], d[e]);
+            else gelu_erf_both((float)pre[e], y[e], d[e]);
+        }
+        // out2: the pre-activation, or (aux_grad) the activation's derivative at it
+        *(bf16x4*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = g.aux_grad ? pack4(d[0], d[1], d[2], d[3]) : pre;
+        *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) = pack4(rs * y[0], rs * y[1], rs * y[2], rs * y[3]);
     } else if constexpr (EPI == EPI_DACT) {
         const bf16x4 pre = fin.aux;
         float d[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            d[e] = (act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
+            d[e] = g.aux_grad ? (float)pre[e] : (act == ACT_QGELU) ? quick_gelu_grad((float)pre[e]) : gelu_erf_grad((float)pre[e]);
         *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) =
             pack4(rs * v[0] * d[0], rs * v[1] * d[1], rs * v[2] * d[2], rs * v[3] * d[3]);
     } else if constexpr (EPI == EPI_F32) {
@@ -115,17 +118,21 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
         bf16x8 pre;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pre[e] = (bf16_t)v[e];
-        *(bf16x8*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = pre;
+        bf16x8 dv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float p = (float)pre[e];
-            o[e] = (bf16_t)(rs * (act == ACT_QGELU ? quick_gelu(p) : gelu_erf(p)));
+            float y, d;
+            if (act == ACT_QGELU) quick_gelu_both((float)pre[e], y, d);
+            else gelu_erf_both((float)pre[e], y, d);
+            o[e] = (bf16_t)(rs * y);
+            dv[e] = (bf16_t)d;
         }
+        *(bf16x8*)((bf16_t*)g.out2 + (long long)m * g.ldo2 + n) = g.aux_grad ? dv : pre;
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float p = (float)aux8[e];
-            o[e] = (bf16_t)(rs * v[e] * (act == ACT_QGELU ? quick_gelu_grad(p) : gelu_erf_grad(p)));
+            o[e] = (bf16_t)(rs * v[e] * (g.aux_grad ? p : act == ACT_QGELU ? quick_gelu_grad(p) : gelu_erf_grad(p)));
         }
     }
     *(bf16x8*)((bf16_t*)g.out + (long long)m * g.ldo + n) = o;
@@ -157,6 +164,7 @@ constexpr int EPI_SCRATCH = EPI_ROWFAC + 128 * 8;   // bytes per wave (fits besi
 static_assert(16 * EPI_RSH >= 8 * EPI_RS, "the fp32 sub-pass scratch must fit in front of the row-factor table");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #ifndef AIM_STORE_POLICY
 #define AIM_STORE_POLICY 2
 #endif
@@ -266,9 +274,30 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                                                      ((long long)m_base * g.ldaux + n_base) * 2, (long long)rows_left * g.ldaux * 2);
         unsigned voA = ncol ? (unsigned)(r8 * g.ldaux + c8) * 2u : AIM_OOB;
         const unsigned stA = (unsigned)g.ldaux * 16u;
+        // aux_frag: out2 (ACT) / aux (DACT) is a FRAGMENT-ordered buffer private to this kernel pair -- [row tile][column tile]
+        // [wave][16x16 tile i * 4 + j][lane] x 4 bf16, the lane's own accumulator elements, so neither side re-tiles it through
+        // LDS: the forward stores 8 bytes per lane (512 contiguous bytes per instruction), the dgrad loads them back.  Both
+        // GEMMs have the same M, N and tiling; the buffer is padded to whole tiles (ops.frag_buffer).
+        const bool afrag = (EPI == EPI_ACT || EPI == EPI_DACT) && g.aux_frag != 0;
+        const long long ftile = ((long long)(m_base >> 8) * ((g.N + 255) >> 8) + (n_base >> 8)) * 8 + (((m_base >> 7) & 1) * 4 + ((n_base >> 6) & 3));
+        const __amdgpu_buffer_rsrc_t rFrag = epi_rsrc(!afrag ? nullptr : EPI == EPI_ACT ? (const void*)g.out2 : (const void*)g.aux,
+                                                      ftile * (32 * 64 * 8), 32 * 64 * 8);
+        const unsigned voF = (unsigned)lane * 8u;
+
         // DACT: the saved pre-activations come in row segments (8 rows x 128 B per load) and cross the scratch the other
         // way, into the MFMA layout, one 16-row tile ahead of their use
         bf16x8 ax[3][2] = {};           // three tiles in flight (a tile is ~1 us of work, a load 2-3 us under load)
+        // aux_frag: the same registers hold three 16-row tiles of fragments (ax[slot][h] = fragments j = 2h, 2h + 1)
+        auto load_frag16 = [&](int slot, int i) {
+            if constexpr (EPI == EPI_DACT) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rFrag, voF + (unsigned)((i * 4 + 2 * h) * 512), 0, AIM_LOAD_POLICY);
+                    const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rFrag, voF + (unsigned)((i * 4 + 2 * h + 1) * 512), 0, AIM_LOAD_POLICY);
+                    ax[slot][h] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                }
+            }
+        };
         auto load_aux16 = [&](int slot) {
             if constexpr (EPI == EPI_DACT) {
                 ax[slot][0] = buf_load_h8(rAux, voA);
@@ -309,15 +338,28 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         // ALLQ: every column of this wave tile takes QuickGELU (all but the adapter's column tile of the fused c_fc GEMM):
         // decided once per tile with a ballot, so the sub-passes carry no per-lane activation branch
         auto run16 = [&](auto ROWF, auto ALLQ) {
-            load_aux16(0);
-            load_aux16(1);
-            load_aux16(2);
+            if (afrag) {
+                load_frag16(0, 0);
+                load_frag16(1, 1);
+                load_frag16(2, 2);
+            } else {
+                load_aux16(0);
+                load_aux16(1);
+                load_aux16(2);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float rs = 1.0f;
                 if constexpr (decltype(ROWF)::value) rs = rowfac[(i * 16 + frow) * 2];
                 bf16x4 o[4], pre[4];
-                if constexpr (EPI == EPI_DACT) {       // this tile's pre-activations: row segments -> MFMA layout (pre[j])
+                if (EPI == EPI_DACT && afrag) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x8 f8 = ax[i % 3][j >> 1];
+                        pre[j] = (j & 1) ? bf16x4{f8[4], f8[5], f8[6], f8[7]} : bf16x4{f8[0], f8[1], f8[2], f8[3]};
+                    }
+                    if (i + 3 < 8) load_frag16(i % 3, i + 3);
+                } else if constexpr (EPI == EPI_DACT) {       // this tile's pre-activations: row segments -> MFMA layout (pre[j])
                     asm volatile("" ::: "memory");
                     *(AIM_LDS bf16x8*)(scr + r8 * EPI_RSH + c8 * 2) = ax[i % 3][0];
                     *(AIM_LDS bf16x8*)(scr + (r8 + 8) * EPI_RSH + c8 * 2) = ax[i % 3][1];
@@ -338,7 +380,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     if constexpr (EPI == EPI_BF16) {
                         o[j] = pack4(rsj * v[0], rsj * v[1], rsj * v[2], rsj * v[3]);
                     } else if constexpr (EPI == EPI_DACT) {
-                        if (decltype(ALLQ)::value || qg[j]) {
+                        if (g.aux_grad) {          // aux holds the activation's derivative already
+                            const f32x2 y0 = (f32x2{v[0], v[1]} * rsj) * f32x2{(float)pre[j][0], (float)pre[j][1]};
+                            const f32x2 y1 = (f32x2{v[2], v[3]} * rsj) * f32x2{(float)pre[j][2], (float)pre[j][3]};
+                            o[j] = pack4(y0[0], y0[1], y1[0], y1[1]);
+                        } else if (decltype(ALLQ)::value || qg[j]) {
                             const f32x2 d0 = quick_gelu_grad2(f32x2{(float)pre[j][0], (float)pre[j][1]});
                             const f32x2 d1 = quick_gelu_grad2(f32x2{(float)pre[j][2], (float)pre[j][3]});
                             const f32x2 y0 = (f32x2{v[0], v[1]} * rsj) * d0, y1 = (f32x2{v[2], v[3]} * rsj) * d1;
@@ -350,17 +396,32 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     } else {
                         pre[j] = pack4(v[0], v[1], v[2], v[3]);
                         if (decltype(ALLQ)::value || qg[j]) {
-                            const f32x2 y0 = quick_gelu2(f32x2{(float)pre[j][0], (float)pre[j][1]}) * rsj;
-                            const f32x2 y1 = quick_gelu2(f32x2{(float)pre[j][2], (float)pre[j][3]}) * rsj;
+                            f32x2 y0, y1, d0, d1;
+                            quick_gelu_both2(f32x2{(float)pre[j][0], (float)pre[j][1]}, y0, d0);
+                            quick_gelu_both2(f32x2{(float)pre[j][2], (float)pre[j][3]}, y1, d1);
+                            y0 *= rsj;
+                            y1 *= rsj;
                             o[j] = pack4(y0[0], y0[1], y1[0], y1[1]);
+                            if (g.aux_grad) pre[j] = pack4(d0[0], d0[1], d1[0], d1[1]);
                         } else {
-                            o[j] = pack4(rsj * gelu_erf((float)pre[j][0]), rsj * gelu_erf((float)pre[j][1]),
-                                         rsj * gelu_erf((float)pre[j][2]), rsj * gelu_erf((float)pre[j][3]));
+                            float y[4], d[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) gelu_erf_both((float)pre[j][e], y[e], d[e]);
+                            o[j] = pack4(rsj * y[0], rsj * y[1], rsj * y[2], rsj * y[3]);
+                            if (g.aux_grad) pre[j] = pack4(d[0], d[1], d[2], d[3]);
                         }
                     }
                 }
                 cross(o, rOut, voO, stO);
-                if constexpr (EPI == EPI_ACT) cross(pre, rOut2, voO2, stO2);
+                if constexpr (EPI == EPI_ACT) {
+                    if (afrag) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pre[j]), rFrag, voF + (unsigned)((i * 4 + j) * 512), 0, AIM_STORE_POLICY);
+                    } else {
+                        cross(pre, rOut2, voO2, stO2);
+                    }
+                }
             }
         };
         const bool allq = EPI != EPI_BF16 && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
@@ -439,7 +500,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w0, true);
                     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], w1, false);
                     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], w1, true);
-                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)w0, (unsigned)w1}, rOut, voO, 0, AIM_STORE_POLICY);
                     epi_advance(voO, stO);
                 } else if constexpr (EPI == EPI_BF16) {

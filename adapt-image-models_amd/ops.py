@@ -66,12 +66,21 @@ def _chk(t: Optional[torch.Tensor], dtype, name: str):
         raise ValueError(f"{name}: innermost dimension must be contiguous")
 
 
+def frag_elems(M: int, N: int) -> int:
+    """Elements of the fragment-ordered side buffer of an ``[M, N]`` ACT / DACT pair (aim_gemm_args.aux_frag)."""
+    return ((M + 255) // 256) * ((N + 255) // 256) * 65536
+
+
+def frag_buffer(M: int, N: int, device) -> torch.Tensor:
+    return torch.empty((frag_elems(M, N),), dtype=BF16, device=device)
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=None, resid=None,
          af=None, at=None, vec=None, bt=None, ntok: int = 0, aux=None, out2=None, act: int = 0,
          scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
          stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldv: Optional[int] = None, n_split: int = 0,
-         act2: int = 0, xrow=None, reserve_cus: int = 0, probe=None):
+         act2: int = 0, xrow=None, reserve_cus: int = 0, probe=None, aux_grad: bool = False, aux_frag: bool = False):
     """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
     lib = load_library()
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -103,6 +112,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     g.xrow = _p(xrow)
     g.ldx = xrow.stride(0) if xrow is not None else 0
     g.reserve_cus = int(reserve_cus)       # per-call: CUs this persistent launch leaves to other streams
+    g.aux_grad = int(bool(aux_grad))       # ACT: out2 = act'(pre) instead of pre; DACT: aux holds act'(pre)
+    g.aux_frag = int(bool(aux_frag))       # ACT / DACT: out2 / aux is a fragment-ordered buffer (frag_buffer)
+    if aux_frag:
+        t_ = out2 if epi == EPI_ACT else aux
+        if epi not in (EPI_ACT, EPI_DACT) or batch != 1 or g.M < 1024 or t_ is None or not t_.is_contiguous() \
+                or t_.numel() < frag_elems(g.M, g.N):
+            raise ValueError("aux_frag: ACT / DACT on the large-tile kernel (M >= 1024, batch 1) with a frag_buffer(M, N)")
+        g.ldo2 = g.ldaux = 0               # (no row stride: the buffer is fragment-ordered)
     if probe is not None:                  # diagnostics (tools/probe_gemm.py): [cap, 4] int64 device tensor
         g.probe, g.probe_cap = probe.data_ptr(), probe.shape[0]
     if epi in (EPI_BF16, EPI_ACT, EPI_DACT):

@@ -100,6 +100,16 @@ typedef struct aim_gemm_args {
     /* per-output-channel dequantisation scale of W (aim_gemm_fp8): acc is multiplied by wscale[n] before bias / act /
        row factors.  NULL -> 1.  */
     const float* wscale;
+    /* AIM_EPI_ACT / AIM_EPI_DACT: what `out2` / `aux` hold.  0: the pre-activation (the DACT epilogue evaluates the
+       derivative from it).  1: the activation's DERIVATIVE at the bf16-rounded pre-activation, computed by the ACT epilogue
+       from the sigmoid / normal CDF it needs anyway -- the DACT epilogue is then dgrad x aux x row factor, no
+       transcendentals (a pre-activation is saved for the backward only: vit_clip.py:80-82,93-97 under autograd). */
+    int32_t aux_grad;
+    /* AIM_EPI_ACT / AIM_EPI_DACT on the large-tile kernel (M >= 1024, batch 1): `out2` / `aux` is a FRAGMENT-ordered buffer,
+       private to the pair of launches with the same M and N: (ceil(M/256) x ceil(N/256) tiles) x [8 waves][32 fragments]
+       [64 lanes] x 4 bf16 -- each lane's own accumulator elements, so neither epilogue re-tiles it (ldo2 / ldaux are
+       ignored; the buffer holds ceil(M/256) * ceil(N/256) * 65536 elements). */
+    int32_t aux_frag;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);

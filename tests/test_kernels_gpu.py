@@ -90,6 +90,27 @@ def test_gemm_act_and_dact(act, M):
     x = pre.float().requires_grad_(True)
     f(x).sum().backward()
     close(out, (g.float() @ w2.float().T) * x.grad, 3e-3, 1.5e-2, "dact")
+    # aux_grad: the forward epilogue stores act'(bf16(pre)) instead of pre (same `post`), the dgrad epilogue multiplies by it
+    post2 = torch.zeros_like(post)
+    dsv = torch.zeros_like(post)
+    ops.gemm(a, w, ops.EPI_ACT, post2, bias=bias, out2=dsv, act=act, aux_grad=True)
+    assert torch.equal(post2, post)
+    close(dsv, x.grad, 2e-3, 1e-2, "stored activation derivative")
+    out2 = torch.zeros_like(out)
+    ops.gemm(g, w2, ops.EPI_DACT, out2, aux=dsv, act=act, aux_grad=True)
+    close(out2, (g.float() @ w2.float().T) * dsv.float(), 3e-3, 1.5e-2, "dact from the stored derivative")
+    close(out2, out, 6e-3, 2e-2, "dact: both forms")
+    if M >= 1024:
+        # aux_frag: the side buffer in the GEMM pair's own fragment order (large-tile kernel only) -- same results, bit for bit
+        for ag in (False, True):
+            fb = ops.frag_buffer(M, N, DEV)
+            post3, out3 = torch.zeros_like(post), torch.zeros_like(out)
+            ops.gemm(a, w, ops.EPI_ACT, post3, bias=bias, out2=fb, act=act, aux_grad=ag, aux_frag=True)
+            ops.gemm(g, w2, ops.EPI_DACT, out3, aux=fb, act=act, aux_grad=ag, aux_frag=True)
+            assert torch.equal(post3, post) and torch.equal(out3, out2 if ag else out)
+    else:
+        with pytest.raises(Exception):
+            ops.gemm(a, w, ops.EPI_ACT, post2, bias=bias, out2=ops.frag_buffer(M, N, DEV), act=act, aux_frag=True)
 
 
 @pytest.mark.parametrize("frames", [4, 200])

@@ -10,11 +10,14 @@ bias = torch.randn(N, device="cuda")
 at = torch.rand(197, device="cuda")
 for epi, nm in ((ops.EPI_ACT, "ACT"), (ops.EPI_DACT, "DACT")):
     out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-    kw = dict(act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU, at=at, ntok=197)
+    kw = dict(act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU, at=at, ntok=197, aux_grad=bool(int(os.environ.get("AUXG", "1"))))
+    frag = bool(int(os.environ.get("FRAG", "1")))
+    kw["aux_frag"] = frag
+    side = ops.frag_buffer(M, N, "cuda").normal_() if frag else torch.randn((M, N), device="cuda").to(torch.bfloat16)
     if epi == ops.EPI_ACT:
-        kw.update(bias=bias, out2=torch.empty_like(out))
+        kw.update(bias=bias, out2=side)
     else:
-        kw.update(aux=torch.randn((M, N), device="cuda").to(torch.bfloat16))
+        kw.update(aux=side)
     for _ in range(2):
         ops.gemm(a, w, epi, out, **kw)
     tiles = 394 * 13
