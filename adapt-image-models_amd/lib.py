@@ -81,7 +81,7 @@ SIGNATURES = {
     "aim_cast_multi": [P, I, P],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load_library():

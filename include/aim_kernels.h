@@ -31,7 +31,7 @@ extern "C" {
 
 typedef uint16_t aim_bf16;
 
-#define AIM_ABI_VERSION 2
+#define AIM_ABI_VERSION 3
 
 int aim_version(void);                /* == AIM_ABI_VERSION */
 const char* aim_last_error(void);     /* message of the last failing call on this thread */
