@@ -255,7 +255,8 @@ _DETACHED_PRIORITY = int(os.environ.get("AIM_DETACHED_PRIORITY", "0"))   # HIP s
 # pre-activation, written by the forward epilogue, instead of the pre-activation itself (aim_gemm_args.aux_grad): the dgrad
 # epilogues lose their exp / rcp.  AIM_AUX_GRAD=0 restores the pre-activation form (A/B runs).
 _AUX_GRAD = os.environ.get("AIM_AUX_GRAD", "1") != "0"
-_AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0"       # ... and the MLP's in the GEMM pair's own fragment order (aux_frag)
+# ... and the MLP's in the GEMM pair's own fragment order (aux_frag; large-tile kernel only, so not under AIM_GEMM_TILE=128)
+_AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0" and os.environ.get("AIM_GEMM_TILE", "") != "128"
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
 
