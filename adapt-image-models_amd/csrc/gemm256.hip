@@ -121,7 +121,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const int tiles_m1 = (g.M + 255) >> 8;
     const int tiles_m = tiles_m1 * nbatch;
     const int nseq = ncols > 0 ? tiles_m * ncols : 0;
-    auto seq_tile = [&](int seq) { return seq < nseq ? (seq / ncols) * tiles_n + c0 + seq % ncols : ntiles; };
+    // (the batched exp-sum GEMM reads what the QKV GEMM has just written: it walks its tiles -- frames -- from the last one
+    //  down, like the other consumers of a just-written tensor: aim_common.h, AIM_REV_BLOCK)
+    constexpr bool walk_down = EPI == EPI_EXPSUM;          // (+0.2 % whole step against the ascending walk)
+    auto seq_tile = [&](int seq) {
+        if (seq >= nseq) return ntiles;
+        const int t = (seq / ncols) * tiles_n + c0 + seq % ncols;
+        return walk_down ? ntiles - 1 - t : t;
+    };
     int seq = rank;
     TileSrc cur = make_tile<ES>(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
     // The next tile is kept as an index only: its descriptors and per-lane row offsets (8 VGPRs) are built in this tile's last
