@@ -36,7 +36,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const bf16_t* __res
     AIM_LDS char* sK = (AIM_LDS char*)smem_raw;
     AIM_LDS char* sV = sK + nkt * 16 * 128;
 
-    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int bid = (int)AIM_REV_BLOCK;          // (frame, head) items from the last one down: aim_common.h
+    const int bt = bid / H, h = bid - bt * H;
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     AIM_LDS float* sL = (AIM_LDS float*)(sO + nq32 * 128);
     AIM_LDS float* sD = sL + nq32;
 
-    const int bt = blockIdx.x / H, h = blockIdx.x - bt * H;
+    const int bid = (int)AIM_REV_BLOCK;          // (frame, head) items from the last one down: aim_common.h
+    const int bt = bid / H, h = bid - bt * H;
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
