@@ -80,7 +80,7 @@ __device__ __forceinline__ TileSrc make_tile(const GemmArgs& g, int tile, int nt
 // (unit block scales): the lane's two 16-byte chunks (ks = 0, 1) are its 32 k-values of that instruction -- any
 // assignment of k to lanes works as long as both operands use the same one (tools/probe_mfma_fp8.hip).
 template <int EPI, bool F8>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int nbatch, int ngroups, int phase_skew,
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, int nbatch, int phase_skew,
                                                       unsigned long long* probe, int probe_cap) {
     constexpr int ES = F8 ? 1 : 2;                // operand element bytes
     constexpr int KT = 128 / ES;                  // elements per K-tile (one 128-byte LDS row)
@@ -100,34 +100,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
     const bool xw = EPI == EPI_EXPSUM && g.xrow != nullptr && wave == ((g.N & 127) >> 4);
     const int nkp = (nk + 1) & ~1;               // K-slots per tile (even)
 
-    // ---- tile schedule: column groups per XCD ---------------------------------------------------
-    // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD; speed only, never
-    // correctness).  The weight matrix is cut into `ngroups` column groups whose slice fits an XCD's
-    // 4 MiB L2 together with the streaming A tiles; XCD x serves group x % ngroups for its share of the
-    // row blocks, walking them column-fastest so the CUs of an XCD share A rows at any moment.
-    //   seq = i * wg_per_group + rank   ->   (tm, tn) = (seq / ncols, c0 + seq % ncols)
-    const bool grouped = (gridDim.x & 7) == 0;                    // otherwise: one group, XCD-contiguous ranks (xcd_remap)
-    const int ng = grouped ? ngroups : 1;
-    const int xcd = grouped ? (int)(blockIdx.x & 7) : 0;
-    const int in_xcd = grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int per_xcd = grouped ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    const int grp = xcd % ng;
-    const int cpg = (tiles_n + ng - 1) / ng;                      // columns per group
-    const int c0 = grp * cpg;
-    const int ncols = min(cpg, tiles_n - c0);                     // may be <= 0 for a trailing empty group
-    const int rank = grouped ? (xcd / ng) * per_xcd + in_xcd      // XCD-major inside the group
-                             : xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int wg_per_group = grouped ? (8 / ng) * per_xcd : (int)gridDim.x;
-    const int tiles_m1 = (g.M + 255) >> 8;
-    const int tiles_m = tiles_m1 * nbatch;
-    const int nseq = ncols > 0 ? tiles_m * ncols : 0;
     // (the batched exp-sum GEMM reads what the QKV GEMM has just written: it walks its tiles -- frames -- from the last one
-    //  down, like the other consumers of a just-written tensor: aim_common.h, AIM_REV_BLOCK)
-    constexpr bool walk_down = EPI == EPI_EXPSUM;          // (+0.2 % whole step against the ascending walk)
+    //  down, like the other consumers of a just-written tensor: aim_common.h, AIM_REV_BLOCK; +0.2 % whole step)
+    constexpr bool walk_down = EPI == EPI_EXPSUM;
+    // ---- tile schedule ---------------------------------------------------------------------------
+    // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD; speed only, never correctness).  The
+    // workgroups of an XCD take CONTIGUOUS ranks, so at any moment an XCD's CUs work on neighbouring tiles of the row-major
+    // tile sequence (shared A rows / W columns in their L2):  tile = rank + i * gridDim.x.  (Column groups per XCD -- a
+    // weight slice resident in each L2 -- were measured twice and removed: the re-fetched weights are Infinity-Cache hits.)
+    const int rank = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3)
+                                          : xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tiles_m1 = (g.M + 255) >> 8;
+    const int wg_per_group = (int)gridDim.x;
+    const int nseq = ntiles;
     auto seq_tile = [&](int seq) {
-        if (seq >= nseq) return ntiles;
-        const int t = (seq / ncols) * tiles_n + c0 + seq % ncols;
-        return walk_down ? ntiles - 1 - t : t;
+        if (seq >= ntiles) return ntiles;
+        return walk_down ? ntiles - 1 - seq : seq;
     };
     int seq = rank;
     TileSrc cur = make_tile<ES>(g, seq_tile(seq), ntiles, tiles_n, tiles_m1, wave, srow, schunk);
@@ -442,16 +430,8 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
         const int need = (tiles + rounds - 1) / rounds;
         if (need < grid) grid = need;       // any size: without a multiple of 8 the kernel ranks its blocks by xcd_remap
     }
-    // column groups: keep each group's weight slice (+ streaming A) inside an XCD's 4 MiB L2
-    int ngroups = 1;
-    static const int force_groups = [] { const char* e = getenv("AIM_GEMM_GROUPS"); return e ? atoi(e) : 0; }();
-    if (grid >= 64 && (grid % 8) == 0) {
-        // measured on MI355X: <= 4 % gain on N >= 3072 and a loss whenever the groups are unbalanced, so the
-        // default is one group; AIM_GEMM_GROUPS = 2 | 4 | 8 is kept for experiments
-        if (force_groups == 2 || force_groups == 4 || force_groups == 8) ngroups = force_groups;
-    }
     static const int phase_skew = [] { const char* e = getenv("AIM_GEMM_SKEW"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, ngroups, phase_skew,
+    hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3(grid), dim3(512), LDS_BYTES, st, g, tiles, nbatch, phase_skew,
                        (unsigned long long*)g.probe, g.probe ? g.probe_cap : 0);
     AIM_CHECK_LAUNCH("aim_gemm_bf16(256)");
     return 0;
