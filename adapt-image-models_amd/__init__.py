@@ -20,7 +20,9 @@ from .aim_variant import AIM  # noqa: E402,F401
 from .recognizer import (CrossEntropyLoss, GPUNormalize, I3DHead, Recognizer3D,  # noqa: E402,F401
                          register_module_hooks, top_k_accuracy)
 
-__all__ += ["BACKBONES", "HEADS", "LOSSES", "MODELS", "RECOGNIZERS", "Config", "Registry", "build_backbone",
+from .dist import DistOptimizerHook, FlatAdamW, build_optimizer  # noqa: E402,F401
+
+__all__ += ["DistOptimizerHook", "FlatAdamW", "build_optimizer", "BACKBONES", "HEADS", "LOSSES", "MODELS", "RECOGNIZERS", "Config", "Registry", "build_backbone",
             "build_from_cfg", "build_head", "build_loss", "build_model", "build_recognizer", "register_into_mmaction",
             "ViT_CLIP", "AIM", "Recognizer3D", "I3DHead", "CrossEntropyLoss", "GPUNormalize", "register_module_hooks",
             "top_k_accuracy"]

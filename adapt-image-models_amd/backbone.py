@@ -257,6 +257,11 @@ _DETACHED_PRIORITY = int(os.environ.get("AIM_DETACHED_PRIORITY", "0"))   # HIP s
 _AUX_GRAD = os.environ.get("AIM_AUX_GRAD", "1") != "0"
 # ... and the MLP's in the GEMM pair's own fragment order (aux_frag; large-tile kernel only, so not under AIM_GEMM_TILE=128)
 _AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0" and os.environ.get("AIM_GEMM_TILE", "") != "128"
+# CUs every large backward GEMM leaves out of its persistent grid (data-parallel runs: room for RCCL's kernels to start beside
+# them).  Default 0: the backward already opens a hole in every shader engine once per layer (the attention backward's 224
+# workgroups) and the LayerNorm backward kernels are short workgroups that free CUs continuously, while a reservation costs
+# every N = 768 GEMM a whole tile round (1 182 tiles: 5 rounds on 256 CUs, 6 on 224: +20 %).  Unmeasured on > 1 GPU.
+_DP_RESERVE = int(os.environ.get("AIM_DP_RESERVE_CUS", "0"))
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
 
@@ -617,13 +622,13 @@ def _mlp_adapter_backward(dyb, x_in, mean2, rstd2, xn, hcat_pre, a_s, dms2, fz: 
         ops.wgrad(dyb, a_s, gm["D_fc2.weight"], gm["D_fc2.bias"], at=dms2, ntok=N)
     dcat = _empty((M, H4 + r), BF16, dev)           # [dh_pre | da_pre]
     ops.gemm(dyb, fz.WcatT2, ops.EPI_DACT, dcat, aux=hcat_pre, act=ops.ACT_QGELU, n_split=H4, act2=ops.ACT_GELU,
-             at=dms2, ntok=N, aux_grad=_AUX_GRAD, aux_frag=_AUX_FRAG and dyb.shape[0] >= 1024)
+             at=dms2, ntok=N, aux_grad=_AUX_GRAD, aux_frag=_AUX_FRAG and dyb.shape[0] >= 1024, reserve_cus=_DP_RESERVE)
     if _DETACH_BIG:
         big_later.append(lambda: ops.wgrad(dcat[:, H4:], xn, gm["D_fc1.weight"], gm["D_fc1.bias"]))
     else:
         ops.wgrad(dcat[:, H4:], xn, gm["D_fc1.weight"], gm["D_fc1.bias"])
     dxn = _empty((M, D), BF16, dev)
-    ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
+    ops.gemm(dcat, fz.WcatT1, ops.EPI_BF16, dxn, reserve_cus=_DP_RESERVE)     # K = 4D + r: frozen c_fc dgrad + adapter D_fc1 dgrad
     dxb = _empty((M, D), BF16, dev)                  # (dcat stays alive in the D_fc1 weight-gradient closure)
     if fsum is not None:
         ops.layernorm_bwd_fsum(dxn, x_in, fz.g2, mean2, rstd2, dyb, dxb, fsum[0], fsum[1], M // N, N, D)
@@ -699,7 +704,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
         fork.run_detached(later, keep)
     # ... beside the spatial attention backward and the fused QKV dgrad on the main stream
     dao = _empty((M, D), BF16, dev)
-    ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N)
+    ops.gemm(dx1b, fz.WoT, ops.EPI_BF16, dao, af=c["oml"], ntok=N, reserve_cus=_DP_RESERVE)
     dqkv = _empty((M, 3 * D), BF16, dev)
     delta = _empty((BT, H, N), F32, dev)
     ops.attn_bwd(c["qkv"], c["ao"], dao, c["lse"], delta, dqkv, BT, N, H)
@@ -708,7 +713,7 @@ def _block_backward(dyb, c, fz: _Frozen, adp: Dict[str, _AdapterW], grads, B, T,
         fork.join()
         ops.cls_attn_bwd(c["qkv"], c["probs"], dot, dqkv, B, T, N, H)
     dxl = _empty((M, D), BF16, dev)
-    ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl)
+    ops.gemm(dqkv, fz.WqkvT, ops.EPI_BF16, dxl, reserve_cus=_DP_RESERVE)
     del dqkv
     if _LATE_JOIN:
         fork.join()
@@ -766,21 +771,37 @@ class _BackboneFn(torch.autograd.Function):
         # blocks
         ctxs: List[Optional[dict]] = []
         training = model.training
-        f8 = model._fp8_operands() if (model.inference_precision == 'fp8' and not need_grad and M >= 1024
-                                       and model.variant == 'vit_clip') else None
+        f8 = None
+        if model.inference_precision == 'fp8' and not need_grad:
+            if M >= 1024 and model.variant == 'vit_clip':
+                f8 = model._fp8_operands()
+            elif not getattr(model, "_fp8_warned", False):
+                model._fp8_warned = True
+                _LOG.warning("fp8 inference was requested but this forward runs bf16: %s",
+                             "the stock-AIM variant has no fp8 path" if model.variant != 'vit_clip'
+                             else "fewer than 1024 token rows (M = %d)" % M)
         masks = model._drop_masks(N, training, dev)          # [L, 2, N]: all layers' DropPath factors in three launches
         aim = model.variant == 'aim'
         if aim:
             from .aim_variant import aim_block_forward
-        for i in range(L):
+        # checkpoint=True (vit_clip.py:316-320, torch.utils.checkpoint per block): the forward keeps each block's INPUT
+        # only (M x D fp32) and the DropPath factors it drew; the backward re-runs the block's forward with them to rebuild
+        # its context (~2 GB per ViT-B layer at 64 clips) just before that block's backward.  Bit-identical gradients
+        # (same kernels, same inputs, same factors), ~1/3 more time, 1 / L of the activation memory.
+        ckpt = bool(model.checkpoint) and need_grad
+
+        def run_block(i, x_in, save):
             dms1, dms2 = masks[i, 0], masks[i, 1]
             if aim:      # stock-AIM block: its first DropPath acts on the un-scaled temporal branch (vitclip_aim.py:205)
                 scale = float(model.transformer.resblocks[i].scale)
-                x, c = aim_block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1 * (1.0 / scale), dms2, need_grad)
-            else:
-                x, c = _block_forward(x, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, need_grad,
-                                      f8=None if f8 is None else f8[i])
-            ctxs.append(c)
+                return aim_block_forward(x_in, frozen["blocks"][i], adp[i], B, T, N, H, dms1 * (1.0 / scale), dms2, save)
+            return _block_forward(x_in, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, save,
+                                  f8=None if f8 is None else f8[i])
+
+        for i in range(L):
+            x_in = x
+            x, c = run_block(i, x_in, need_grad and not ckpt)
+            ctxs.append(dict(recompute=run_block, x_in=x_in) if ckpt else c)
         # ln_post on the class rows only (LayerNorm is per-row; vit_clip.py:452-453)
         gw, gb = lnp_w.detach().float().contiguous(), lnp_b.detach().float().contiguous()
         y = _empty((BT, D), F32, dev)
@@ -839,8 +860,11 @@ class _BackboneFn(torch.autograd.Function):
         if model.variant == 'aim':
             from .aim_variant import aim_block_backward as blk_bwd
         for i in reversed(range(L)):
-            dxb = blk_bwd(dxb, s["ctxs"][i], frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
-            s["ctxs"][i] = None
+            c = s["ctxs"][i]
+            if "recompute" in c:        # checkpoint=True: rebuild this block's context from its saved input
+                c = c["recompute"](i, c["x_in"], True)[1]
+            dxb = blk_bwd(dxb, c, frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
+            s["ctxs"][i] = c = None
             if hook is not None:
                 # every kernel that accumulates into the gradients of layers >= i has been QUEUED (adapter weight
                 # gradients on the detached stream): the data-parallel optimizer may start reducing that slice of the
@@ -887,7 +911,7 @@ class ViT_CLIP(nn.Module):
         self.num_frames = num_frames
         self.temporal_embedding = nn.Parameter(torch.zeros(1, num_frames, width))
         self.shift = shift
-        self.checkpoint = checkpoint   # accepted for config compatibility; activations fit in 288 GB HBM
+        self.checkpoint = checkpoint   # per-block activation recompute in the backward (vit_clip.py:316-320; _BackboneFn)
         self.transformer = Transformer(num_frames, width, layers, heads, scale=adapter_scale, drop_path=drop_path_rate)
         self.ln_post = LayerNorm(width)
         self._frozen_cache = None
@@ -895,6 +919,7 @@ class ViT_CLIP(nn.Module):
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
         self.grad_ready_hook = None                 # fn(layer, in_place, streams): set by dist.FlatAdamW (overlapped all-reduce)
         self._fp8_cache = None
+        self.weights_epoch = 0                      # bumped by dist.FlatAdamW.step(): trainable weights changed in place
         self.variant = 'vit_clip'                   # 'aim': the stock-AIM block (aim_variant.py)
         # inference precision of the large GEMMs: 'bf16' (default, the training kernels) or 'fp8' (BASELINE configs[4]:
         # fp8 e4m3 operands on the block-scaled MFMA; no-grad forwards only).  AIM_INFER_FP8=1 selects fp8 globally.
@@ -992,7 +1017,8 @@ class ViT_CLIP(nn.Module):
 
     def _fp8_operands(self):
         """Per-block fp8 operands; rebuilt only when any block weight changed or moved."""
-        key = tuple((p.data_ptr(), p._version) for p in self.transformer.parameters())
+        # (FlatAdamW updates the adapters through raw pointers -- no tensor version changes -- and bumps `weights_epoch`)
+        key = tuple((p.data_ptr(), p._version) for p in self.transformer.parameters()) + (self.weights_epoch,)
         if self._fp8_cache is None or self._fp8_cache[0] != key:
             self._fp8_cache = (key, [_Frozen8(b) for b in self.transformer.resblocks])
         return self._fp8_cache[1]

@@ -8,9 +8,9 @@ typedef aim_gemm_args GemmArgs;
 enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, EPI_F32 = AIM_EPI_F32, EPI_EXPSUM = AIM_EPI_EXPSUM, EPI_ACT8 = AIM_EPI_ACT8 };
 enum { ACT_QGELU = AIM_ACT_QGELU, ACT_GELU = AIM_ACT_GELU };
 
-// CUs a launch on `st` can use: the stream's CU mask (hipExtStreamCreateWithCUMask: the caller may keep a few CUs out of its
-// main stream for the small kernels of another stream) or the device's CU count.  Persistent kernels size their grids by it.
-int aim_stream_cus(hipStream_t st);
+// CUs of the current device (per-call query, no cache; CU-masked caller streams are not supported: capi.hip).  Persistent
+// kernels size their grids by it.
+int aim_device_cus();
 int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st);
 int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st);
 int aim_gemm256_fp8_launch(const GemmArgs& g, int epi, hipStream_t st);

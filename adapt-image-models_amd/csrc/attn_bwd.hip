@@ -849,7 +849,7 @@ extern "C" int aim_attn_bwd(const aim_bf16* qkv, const aim_bf16* out, const aim_
             attr_set2 = true;
         }
         const int items = BT * H;
-        int cus = aim_stream_cus(st);
+        int cus = aim_device_cus();
         // The grid is persistent (one workgroup per CU for the whole launch), and the hardware deals workgroups to XCDs and
         // shader engines in launch order (workgroup i -> XCD i % 8 -> engine (i / 8) % 4) and makes a workgroup WAIT for a CU of
         // its engine even when other engines have one free (tools/cumask_probe.hip, tools/cumask_gemm.py).  With every CU

@@ -13,45 +13,19 @@ void aim_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Stream -> usable CUs.  A small lock-free cache (a stream's mask never changes): the query is a runtime call per launch
-// otherwise.  Entries are only ever added; a full table falls back to the query.
-#include <atomic>
-int aim_stream_cus(hipStream_t st) {
-    static const int dev_cus = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus > 0 ? cus : 256;
-    }();
-    if (st == nullptr) return dev_cus;
-    constexpr int SLOTS = 32;
-    static std::atomic<void*> keys[SLOTS];
-    static std::atomic<int> vals[SLOTS];
-    for (int i = 0; i < SLOTS; ++i) {
-        void* k = keys[i].load(std::memory_order_acquire);
-        if (k == (void*)st) {
-            const int v = vals[i].load(std::memory_order_acquire);
-            if (v > 0) return v;
-        }
-        if (k == nullptr) break;
-    }
-    uint32_t mask[16] = {0};
-    int cus = dev_cus;
-    if (hipExtStreamGetCUMask(st, 16, mask) == hipSuccess) {
-        int bits = 0;
-        for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
-        if (bits > 0 && bits < dev_cus) cus = bits;
-    } else {
+// CUs of the device the calling thread has current: what a persistent kernel sizes its grid by.  Queried per call (a
+// table lookup inside the runtime, ~0.1 us), nothing cached: the library keeps no state between calls.  CU-MASKED caller
+// streams (hipExtStreamCreateWithCUMask) are NOT part of the ABI: measured in round 2, a masked main stream makes the
+// persistent GEMM 41 % slower (the dispatcher still stripes workgroups over engines that now have fewer CUs), and the one
+// abort in that experiment's records sat in the masked stream's teardown under the profiler -- a caller that wants CUs kept
+// out of a launch passes aim_gemm_args.reserve_cus instead.
+int aim_device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
+        return 256;
     }
-    for (int i = 0; i < SLOTS; ++i) {
-        void* expect = nullptr;
-        if (keys[i].compare_exchange_strong(expect, (void*)st, std::memory_order_acq_rel)) {
-            vals[i].store(cus, std::memory_order_release);
-            break;
-        }
-        if (expect == (void*)st) break;
-    }
-    return cus;
+    return cus > 0 ? cus : 256;
 }
 
 extern "C" int aim_version(void) { return AIM_ABI_VERSION; }

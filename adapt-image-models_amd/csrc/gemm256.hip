@@ -418,7 +418,7 @@ int launch256(const GemmArgs& g, int nbatch, hipStream_t st) {
     // a persistent grid that fills every CU starves whatever runs beside it on another stream: the caller can keep a few
     // CUs out of the grid while such work is in flight
     const int reserve = g.reserve_cus > 0 ? g.reserve_cus : 0;       // per-call knob (aim_gemm_args.reserve_cus)
-    const int ncu = aim_stream_cus(st);                     // the stream's CU mask, or the device
+    const int ncu = aim_device_cus();
     const int cus = ncu - reserve > 8 ? ncu - reserve : 8;
     int grid = tiles < cus ? tiles : cus;
     // balanced grid: the fewest workgroups that still finish in ceil(tiles / cus) rounds.  1 182 tiles take 5 rounds on 256

@@ -40,20 +40,35 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
-// per sample: softmax, loss term, rank of the label (numpy argsort tie order), dscore row
+// per sample: softmax, loss term, rank of the label (numpy argsort tie order), dscore row.
+// A label outside [0, C) is IGNORED the way F.cross_entropy ignores ignore_index = -100 (the call this replaces,
+// cross_entropy_loss.py:78): no loss term, a zero dscore row, and the mean runs over the valid samples only (torch
+// device-asserts on other out-of-range labels; here they are ignored as well instead of read out of bounds).  The two
+// accuracy columns keep the reference's denominator B (heads/base.py:90-95 counts such a sample as a miss).
 __global__ __launch_bounds__(256) void ce_topk_kernel(const float* __restrict__ score, const long long* __restrict__ label,
                                                       float* __restrict__ dscore, float* __restrict__ per_sample, int B,
                                                       int C, int k2) {
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = score + (long long)b * C;
-    const int lab = (int)label[b];
+    const long long lab64 = label[b];
+    const bool valid = lab64 >= 0 && lab64 < (long long)C;
+    const int lab = valid ? (int)lab64 : 0;
+    // valid samples of the batch (every workgroup counts them itself: B is a few dozen labels)
+    float nv = 0.f;
+    for (int i = tid; i < B; i += 256) {
+        const long long l = label[i];
+        nv += (l >= 0 && l < (long long)C) ? 1.f : 0.f;
+    }
+    nv = wave_sum(nv);
+    if (lane == 0) red[4 + wave] = nv;
     float mx = -INFINITY;
     for (int c = tid; c < C; c += 256) mx = fmaxf(mx, s[c]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    nv = red[4] + red[5] + red[6] + red[7];
     __syncthreads();
     const float tgt = s[lab];
     float sum = 0.f, ahead = 0.f;
@@ -68,24 +83,25 @@ __global__ __launch_bounds__(256) void ce_topk_kernel(const float* __restrict__ 
     __syncthreads();
     sum = red[0] + red[1] + red[2] + red[3];
     ahead = red[4] + red[5] + red[6] + red[7];
-    const float lse = mx + __logf(sum), invB = 1.0f / (float)B;
+    const float lse = mx + __logf(sum), inv = valid ? 1.0f / nv : 0.f;
     if (dscore)
         for (int c = tid; c < C; c += 256)
-            dscore[(long long)b * C + c] = (__expf(s[c] - lse) - (c == lab ? 1.f : 0.f)) * invB;
+            dscore[(long long)b * C + c] = valid ? (__expf(s[c] - lse) - (c == lab ? 1.f : 0.f)) * inv : 0.f;
     if (tid == 0) {
-        per_sample[b * 3 + 0] = lse - tgt;
-        per_sample[b * 3 + 1] = ahead < 1.f ? 1.f : 0.f;
-        per_sample[b * 3 + 2] = ahead < (float)(k2 < C ? k2 : C) ? 1.f : 0.f;
+        per_sample[b * 4 + 0] = valid ? lse - tgt : 0.f;
+        per_sample[b * 4 + 1] = (valid && ahead < 1.f) ? 1.f : 0.f;
+        per_sample[b * 4 + 2] = (valid && ahead < (float)(k2 < C ? k2 : C)) ? 1.f : 0.f;
+        per_sample[b * 4 + 3] = valid ? 1.f : 0.f;
     }
 }
 
-// ordered sum over the samples (bitwise reproducible): out3 = means of the three per-sample columns
+// ordered sum over the samples (bitwise reproducible): out3 = [CE mean over the valid samples, top-1, top-k2 over B]
 __global__ __launch_bounds__(64) void ce_finish_kernel(const float* __restrict__ per_sample, float* __restrict__ out3, int B) {
     const int j = threadIdx.x;
     if (j < 3) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += per_sample[b * 3 + j];
-        out3[j] = s / (float)B;
+        float s = 0.f, n = 0.f;
+        for (int b = 0; b < B; ++b) { s += per_sample[b * 4 + j]; n += per_sample[b * 4 + 3]; }
+        out3[j] = s / (j == 0 ? n : (float)B);
     }
 }
 

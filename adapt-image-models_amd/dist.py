@@ -131,8 +131,14 @@ class FlatAdamW:
         self._works = []
         self._reduced = []           # ranges already handed to the collective in this step
         self._sync = True
+        self._summed = False         # flat_g holds the SUM over ranks (this step's collective has run)
         self._comm = None
         self.early_launches = 0      # diagnostics: collectives started from inside backward
+        # early buckets start from inside backward (the caller promises ONE backward per synchronised step; more than one
+        # raises, see _on_layer_queued).  False / AIM_DP_OVERLAP=0: one reduction inside step() after any number of backwards
+        self.overlap = os.environ.get("AIM_DP_OVERLAP", "1") != "0"
+        self._top_layer = -1
+        self._backbones = []         # attached backbones: told when their trainable weights changed (fp8 operand caches)
         self.force_collectives = False
 
     # ---- overlapped all-reduce ---------------------------------------------------------------------------------
@@ -165,6 +171,8 @@ class FlatAdamW:
             if b - a == sum(pad(pos[id(p)][1]) for p in ps):
                 self._buckets.append((lo, a, b))
         backbone.grad_ready_hook = self._on_layer_queued
+        self._top_layer = L - 1
+        self._backbones.append(backbone)
         return self._buckets
 
     @contextlib.contextmanager
@@ -177,8 +185,16 @@ class FlatAdamW:
             self._sync = old
 
     def _on_layer_queued(self, layer: int, in_place: bool, streams):
-        if not self._sync or not self._active() or not in_place:
+        if not self._sync or not self._active() or not in_place or not self.overlap:
             return
+        if layer == self._top_layer and self._reduced:
+            # DDP reduces on every backward; here a step's gradients are reduced ONCE (the mean of the sum = the sum of
+            # the means), so a backward that arrives after the reduction has started would add local gradients to
+            # already-summed buckets.  Never silently: the reference's accumulation contract (update_interval > 1,
+            # mmaction/utils/optimizer.py:22-33) is served by no_sync() / aim_amd.DistOptimizerHook or overlap = False.
+            raise RuntimeError("FlatAdamW: backward() after this step's gradient reduction has started; wrap the "
+                               "non-boundary micro-steps in opt.no_sync() (aim_amd.DistOptimizerHook does) or set "
+                               "opt.overlap = False (one reduction inside step(), any number of backwards)")
         for lo, a, b in self._buckets:
             if lo == layer and (a, b) not in self._reduced:
                 self._launch(a, b, streams)
@@ -197,6 +213,9 @@ class FlatAdamW:
         self.early_launches += 1
 
     def zero_grad(self, set_to_none: bool = False):
+        for w in self._works:                           # (a reduction nobody waited for must not land in the zeroed buffer)
+            w.wait()
+        self._works, self._reduced, self._summed = [], [], False
         self.flat_g.zero_()
         for p, off, n in self._views:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
@@ -205,7 +224,9 @@ class FlatAdamW:
     def all_reduce_grads(self):
         """Finish the step's gradient reduction (SUM over ranks; the mean's 1/world is applied inside ``step``): reduce
         whatever the early buckets did not cover -- everything, when no backbone is attached -- and make the current
-        stream wait for all of it."""
+        stream wait for all of it.  Idempotent within a step: a second call finds nothing left.  After it ``flat_g`` /
+        ``param.grad`` hold the SUM over ranks (DDP leaves the mean there): ``grad_scale`` is the factor that turns
+        them into DDP's mean, and ``clip_grad_norm_`` accounts for it."""
         if not self._active() or not self._sync:
             return
         todo, cur = [], 0
@@ -217,19 +238,44 @@ class FlatAdamW:
             todo.append((cur, self.numel))
         for a, b in todo:
             self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+            self._reduced.append((a, b))
         for w in self._works:
             w.wait()                                    # stream-ordered on GPU backends: no host sync
-        self._works, self._reduced = [], []
+        self._works = []
+        self._summed = True                             # flat_g now holds the SUM over ranks
+
+    @property
+    def grad_scale(self) -> float:
+        """What turns ``param.grad`` into the data-parallel MEAN gradient right now: 1/world after this step's
+        all-reduce ran (the collective is a SUM), 1 before it or inside ``no_sync()`` (local gradients)."""
+        return 1.0 / self._world() if self._summed else 1.0
+
+    def clip_grad_norm_(self, max_norm: float, norm_type: float = 2.0):
+        """mmcv ``OptimizerHook(grad_clip=dict(max_norm=...))`` on the flat buffer (the reference's sgd schedules use
+        ``max_norm=40``): the norm is taken of the MEAN gradient (``grad_scale`` applied), like
+        ``torch.nn.utils.clip_grad_norm_`` sees it under DDP.  Finishes a pending reduction first; returns the norm."""
+        self.all_reduce_grads()
+        total = torch.linalg.vector_norm(self.flat_g, norm_type) * self.grad_scale
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        self.flat_g.mul_(coef)
+        return total
 
     def step(self):
+        """One AdamW step.  The reference's hook contract is ``loss.backward(); optimizer.step()``
+        (mmaction/utils/optimizer.py:22-33: DDP has finished its buckets when backward returns): a step therefore first
+        launches whatever part of the gradient reduction is still outstanding and waits for all of it (stream-ordered),
+        so a caller that never calls ``all_reduce_grads()`` itself still steps on fully reduced gradients."""
+        self.all_reduce_grads()
         self.step_count += 1
-        gs = 1.0 / self._world()                        # SUM all-reduce -> mean, inside the optimizer kernel
+        gs = self.grad_scale                            # SUM all-reduce -> mean, inside the optimizer kernel
         for grp in self.param_groups:
             a, b = grp["range"]
             if b > a:
                 self._ops.adamw_flat(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], grp["lr"],
                                      grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self.step_count,
                                      grad_scale=gs)
+        for bb in self._backbones:                      # the update went through raw pointers: no tensor version changed
+            bb.weights_epoch = getattr(bb, "weights_epoch", 0) + 1
 
     def state_dict(self):
         """torch.optim-shaped: ``state`` = per-parameter {step, exp_avg, exp_avg_sq} keyed by the parameter's index in
@@ -278,6 +324,43 @@ class FlatAdamW:
         if len(steps) > 1:
             raise ValueError("FlatAdamW keeps one step count for all parameters")
         self.step_count = steps.pop() if steps else 0
+
+
+class DistOptimizerHook:
+    """The reference's optimizer hook (mmaction/utils/optimizer.py:9-33) for ``FlatAdamW``: ``loss /= update_interval``,
+    backward on every iteration, clip + step + zero_grad on every ``update_interval``-th.  Same constructor keywords
+    (``coalesce`` / ``bucket_size_mb`` are accepted and unused there too; ``use_fp16`` selected apex loss scaling, which
+    the bf16 policy does not need).  Unlike the reference -- whose DDP all-reduces on every micro-step -- only the
+    boundary micro-step communicates: the others run inside ``no_sync()``."""
+
+    def __init__(self, update_interval=1, grad_clip=None, coalesce=True, bucket_size_mb=-1, use_fp16=False):
+        self.grad_clip = grad_clip
+        self.coalesce = coalesce
+        self.bucket_size_mb = bucket_size_mb
+        self.update_interval = update_interval
+        self.use_fp16 = use_fp16
+
+    def before_run(self, runner):
+        runner.optimizer.zero_grad()
+
+    def every_n_iters(self, runner, n):
+        return (runner.iter + 1) % n == 0 if n > 0 else False
+
+    def after_train_iter(self, runner):
+        opt = runner.optimizer
+        runner.outputs['loss'] /= self.update_interval
+        boundary = self.every_n_iters(runner, self.update_interval)
+        ctx = contextlib.nullcontext() if (boundary or not hasattr(opt, "no_sync")) else opt.no_sync()
+        with ctx:
+            runner.outputs['loss'].backward()
+        if boundary:
+            if self.grad_clip is not None:
+                if hasattr(opt, "clip_grad_norm_"):
+                    opt.clip_grad_norm_(**self.grad_clip)
+                else:
+                    torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], **self.grad_clip)
+            opt.step()
+            opt.zero_grad()
 
 
 def shard_indices(n: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True):

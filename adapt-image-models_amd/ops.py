@@ -458,7 +458,7 @@ def ce_topk(score, label, k2: int = 5, need_grad: bool = True):
     B, C = score.shape
     assert score.is_contiguous() and label.numel() == B
     dscore = torch.empty_like(score) if need_grad else None
-    ws = torch.empty((B, 3), dtype=F32, device=score.device)
+    ws = torch.empty((B, 4), dtype=F32, device=score.device)
     out3 = torch.empty((3,), dtype=F32, device=score.device)
     check(load_library().aim_ce_topk(score.data_ptr(), label.data_ptr(), _p(dscore), ws.data_ptr(), out3.data_ptr(), B, C,
                                      k2, _stream()), "aim_ce_topk")

@@ -2,7 +2,7 @@
 
 * ``Recognizer3D``  -- mmaction/models/recognizers/recognizer3d.py:8-118 + base.py:14-330
 * ``I3DHead``       -- mmaction/models/heads/i3d_head.py:9-73 + heads/base.py:27-108
-* ``CrossEntropyLoss`` -- mmaction/models/losses/cross_entropy_loss.py:9-80 (hard and soft labels)
+* ``CrossEntropyLoss`` -- mmaction/models/losses/cross_entropy_loss.py:9-80 (the hard-label branch, :78)
 * ``top_k_accuracy``   -- mmaction/core/evaluation/accuracy.py:90-109
 * ``GPUNormalize`` / ``register_module_hooks`` -- mmaction/utils/module_hooks.py:8-87 (fused into the
   patch-embedding kernel when the hooked module is this package's ``ViT_CLIP``).
@@ -12,9 +12,11 @@ HIP kernels of libaim_hip.so: ``aim_head_fwd/bwd`` (avg-po
 and ``aim_ce_topk`` (hard-label cross-entropy + top-1/top-5 in one launch, no ``.cpu().numpy()`` sync per iteration,
 heads/base.py:90).  ``_parse_losses`` reduces the log scalars in ONE all-reduce instead of four
 (recognizers/base.py:237-242) and hands them back as lazily materialised floats (no host sync until a logger reads
-them).  Plain PyTorch ops remain for what the K400 configs never use on this path (soft labels, class weights,
-multi_class heads, non-average pooling) and for CPU tensors in host-logic tests; if the HIP library is missing, a GPU
-call raises ``LibraryNotBuilt`` -- it never falls back.
+them).  What the vit configs never use on this path -- soft labels, class weights, label smoothing, multi_class heads,
+non-average pooling, feature extraction, gradcam, backward hooks -- is NOT restated here: those keywords raise
+``NotImplementedError`` and belong to a real mmaction install (``register_into_mmaction``).  CPU tensors take a plain
+``F.cross_entropy`` / ``nn.Linear`` (host-logic tests only); if the HIP library is missing, a GPU call raises
+``LibraryNotBuilt`` -- it never falls back.
 """
 from collections import OrderedDict
 
@@ -140,32 +142,21 @@ class _CETopkFn(torch.autograd.Function):
 
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
+    """Hard-label cross entropy (cross_entropy_loss.py:78) times ``loss_weight`` (losses/base.py)."""
+
     def __init__(self, loss_weight=1.0, class_weight=None):
         super().__init__()
+        if class_weight is not None:
+            raise NotImplementedError("CrossEntropyLoss(class_weight=...) is outside the AIM ViT-CLIP path")
         self.loss_weight = loss_weight
-        self.class_weight = None if class_weight is None else torch.Tensor(class_weight)
+        self.class_weight = None
 
-    def _forward(self, cls_score, label, **kwargs):
-        if cls_score.size() == label.size():
-            assert cls_score.dim() == 2, 'Only support 2-dim soft label'
-            assert len(kwargs) == 0, f'For now, no extra args are supported for soft label, but get {kwargs}'
-            lsm = F.log_softmax(cls_score, 1)
-            if self.class_weight is not None:
-                self.class_weight = self.class_weight.to(cls_score.device)
-                lsm = lsm * self.class_weight.unsqueeze(0)
-            loss_cls = -(label * lsm).sum(1)
-            if self.class_weight is not None:
-                return loss_cls.sum() / torch.sum(self.class_weight.unsqueeze(0) * label)
-            return loss_cls.mean()
-        if self.class_weight is not None:
-            assert 'weight' not in kwargs, "The key 'weight' already exists."
-            kwargs['weight'] = self.class_weight.to(cls_score.device)
-        if cls_score.is_cuda and not kwargs and cls_score.dim() == 2 and label.dtype == torch.int64:
-            return _CETopkFn.apply(cls_score, label)[0]          # hard labels on the GPU: aim_ce_topk
-        return F.cross_entropy(cls_score, label, **kwargs)
-
-    def forward(self, *args, **kwargs):
-        return self._forward(*args, **kwargs) * self.loss_weight
+    def forward(self, cls_score, label, **kwargs):
+        if kwargs or cls_score.size() == label.size():
+            raise NotImplementedError("soft labels / extra cross_entropy arguments are outside the AIM ViT-CLIP path")
+        if cls_score.is_cuda and cls_score.dim() == 2 and label.dtype == torch.int64:
+            return _CETopkFn.apply(cls_score, label)[0] * self.loss_weight      # aim_ce_topk
+        return F.cross_entropy(cls_score, label) * self.loss_weight
 
 
 @HEADS.register_module()
@@ -175,59 +166,50 @@ class I3DHead(nn.Module):
     def __init__(self, num_classes, in_channels, loss_cls=dict(type='CrossEntropyLoss'), spatial_type='avg',
                  dropout_ratio=0.5, init_std=0.01, multi_class=False, label_smooth_eps=0.0, **kwargs):
         super().__init__()
+        if multi_class or label_smooth_eps != 0.0 or spatial_type != 'avg':
+            raise NotImplementedError("I3DHead: multi_class / label_smooth_eps / spatial_type != 'avg' are outside the "
+                                      "AIM ViT-CLIP path (every vit config uses the defaults)")
         self.num_classes, self.in_channels = num_classes, in_channels
         self.loss_cls = build_loss(loss_cls)
-        self.multi_class, self.label_smooth_eps = multi_class, label_smooth_eps
+        self.multi_class, self.label_smooth_eps = False, 0.0
         self.spatial_type, self.dropout_ratio, self.init_std = spatial_type, dropout_ratio, init_std
         self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
         self.fc_cls = nn.Linear(in_channels, num_classes)
-        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1)) if spatial_type == 'avg' else None
 
     def init_weights(self):
         nn.init.normal_(self.fc_cls.weight, 0, self.init_std)   # mmcv normal_init
         nn.init.constant_(self.fc_cls.bias, 0)
 
     def forward(self, x):
-        if x.is_cuda and self.avg_pool is not None and x.dim() == 5:
-            # [B, C, T, H, W] -> [B, T*H*W, C]; the backbone's [B, D, T, 1, 1] output is a view of a frame-major
-            # [B, T, D] buffer, so this is free.  Dropout is a caller-drawn factor table (same semantics as nn.Dropout
-            # on the pooled [B, C] features: bernoulli(1 - p) / (1 - p)).
-            feat = x.flatten(2).permute(0, 2, 1).contiguous()
+        # [B, C, T, H, W] -> [B, T*H*W, C]; the backbone's [B, D, T, 1, 1] output is a view of a frame-major [B, T, D]
+        # buffer, so this is free.  Dropout is a caller-drawn factor table (same semantics as nn.Dropout on the pooled
+        # [B, C] features: bernoulli(1 - p) / (1 - p)).
+        feat = x.flatten(2).permute(0, 2, 1).contiguous()
+        if x.is_cuda:
             drop = None
             if self.dropout is not None and self.training:
                 keep = 1.0 - self.dropout_ratio
                 drop = torch.empty((feat.shape[0], feat.shape[2]), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
             return _HeadFn.apply(feat, drop, self.fc_cls.weight, self.fc_cls.bias)
-        if self.avg_pool is not None:
-            x = self.avg_pool(x)
+        pooled = feat.mean(1)                                    # CPU tensors: host-logic tests
         if self.dropout is not None:
-            x = self.dropout(x)
-        return self.fc_cls(x.view(x.shape[0], -1))
+            pooled = self.dropout(pooled)
+        return self.fc_cls(pooled)
 
     def loss(self, cls_score, labels, **kwargs):
-        """heads/base.py:68-108."""
+        """heads/base.py:68-108 for hard labels: top-1 / top-5 accuracy + ``loss_cls``."""
+        if kwargs:
+            raise NotImplementedError("extra loss arguments are outside the AIM ViT-CLIP path")
         losses = dict()
         if labels.shape == torch.Size([]):
             labels = labels.unsqueeze(0)
-        elif labels.dim() == 1 and labels.size()[0] == self.num_classes and cls_score.size()[0] == 1:
-            labels = labels.unsqueeze(0)
-        if (not self.multi_class and cls_score.size() != labels.size() and cls_score.is_cuda and not kwargs
-                and isinstance(self.loss_cls, CrossEntropyLoss) and self.loss_cls.class_weight is None
-                and cls_score.dim() == 2 and labels.dtype == torch.int64):
+        if cls_score.is_cuda and cls_score.dim() == 2 and labels.dtype == torch.int64:
             out3 = _CETopkFn.apply(cls_score, labels)        # CE + top-1/top-5 in one launch, nothing leaves the GPU
             losses['top1_acc'], losses['top5_acc'] = out3[1].detach(), out3[2].detach()
             losses['loss_cls'] = out3[0] * self.loss_cls.loss_weight
             return losses
-        if not self.multi_class and cls_score.size() != labels.size():
-            top1, top5 = top_k_accuracy_device(cls_score, labels, (1, 5))
-            losses['top1_acc'], losses['top5_acc'] = top1, top5
-        elif self.multi_class and self.label_smooth_eps != 0:
-            labels = (1 - self.label_smooth_eps) * labels + self.label_smooth_eps / self.num_classes
-        loss_cls = self.loss_cls(cls_score, labels, **kwargs)
-        if isinstance(loss_cls, dict):
-            losses.update(loss_cls)
-        else:
-            losses['loss_cls'] = loss_cls
+        losses['top1_acc'], losses['top5_acc'] = top_k_accuracy_device(cls_score, labels, (1, 5))
+        losses['loss_cls'] = self.loss_cls(cls_score, labels)
         return losses
 
 
@@ -248,7 +230,8 @@ class Recognizer3D(nn.Module):
         if test_cfg is not None and 'max_testing_views' in test_cfg:
             self.max_testing_views = test_cfg['max_testing_views']
             assert isinstance(self.max_testing_views, int)
-        self.feature_extraction = bool(test_cfg and test_cfg.get('feature_extraction', False))
+        if test_cfg and test_cfg.get('feature_extraction', False):
+            raise NotImplementedError("test_cfg.feature_extraction is outside the AIM ViT-CLIP path")
         self.blending = None
         self.init_weights()
         self.fp16_enabled = False
@@ -291,7 +274,7 @@ class Recognizer3D(nn.Module):
         return dict(self.cls_head.loss(cls_score, gt_labels, **kwargs))
 
     def _do_test(self, imgs):
-        batches, num_segs = imgs.shape[0], imgs.shape[1]
+        num_segs = imgs.shape[1]
         imgs = imgs.reshape((-1,) + imgs.shape[2:])
         if self.max_testing_views is not None:
             total_views = imgs.shape[0]
@@ -301,9 +284,6 @@ class Recognizer3D(nn.Module):
             feat = torch.cat(feats)
         else:
             feat = self.extract_feat(imgs)
-        if self.feature_extraction:
-            feat = F.adaptive_avg_pool3d(feat, 1).reshape((batches, num_segs, -1))
-            return feat.mean(axis=1)
         assert self.with_cls_head
         return self.average_clip(self.cls_head(feat), num_segs)
 
@@ -317,9 +297,6 @@ class Recognizer3D(nn.Module):
         if softmax:
             outs = F.softmax(outs, dim=-1)
         return (outs,)
-
-    def forward_gradcam(self, imgs):
-        return self._do_test(imgs)
 
     @staticmethod
     def _parse_losses(losses):
@@ -341,8 +318,7 @@ class Recognizer3D(nn.Module):
 
     def forward(self, imgs, label=None, return_loss=True, **kwargs):
         if kwargs.get('gradcam', False):
-            del kwargs['gradcam']
-            return self.forward_gradcam(imgs, **kwargs)
+            raise NotImplementedError("gradcam is outside the AIM ViT-CLIP path")
         if return_loss:
             if label is None:
                 raise ValueError('Label should not be None.')
@@ -403,9 +379,7 @@ def register_module_hooks(Module, module_hooks_list):
             handle = hooked_module.register_forward_pre_hook(module_hook.hook_func())
         elif hook_pos == 'forward':
             handle = hooked_module.register_forward_hook(module_hook.hook_func())
-        elif hook_pos == 'backward':
-            handle = hooked_module.register_backward_hook(module_hook.hook_func())
         else:
-            raise ValueError(f'hook_pos must be `forward_pre`, `forward` or `backward`, but get {hook_pos}')
+            raise ValueError(f'hook_pos must be `forward_pre` or `forward` here (backward hooks: use mmaction), but get {hook_pos}')
         handles.append(handle)
     return handles

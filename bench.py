@@ -144,8 +144,7 @@ def secondary_l14(dev, rank, world, steps=3, warmup=1, clips=32, frames=16):
         opt.zero_grad()
         loss = model(imgs, label, return_loss=True)["loss_cls"]
         loss.backward()
-        opt.all_reduce_grads()
-        opt.step()
+        opt.step()                  # (finishes the gradient reduction the backward started: dist.FlatAdamW.step)
         return loss
 
     def fence():
@@ -264,9 +263,8 @@ def main():
         losses = model(imgs, label, return_loss=True)
         loss = losses["loss_cls"]
         loss.backward()
-        opt.all_reduce_grads()
-        opt.step()
-        return losses
+        opt.step()                  # the reference's hook contract (mmaction/utils/optimizer.py:22-33): step() finishes the
+        return losses               # adapter-gradient all-reduce whose first two buckets started inside backward
 
     def fence():
         if world > 1:
@@ -358,7 +356,9 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
         try:
             sec = secondary_l14(dev, rank, world)
-        except Exception as e:          # the primary line must still be printed
+        except Exception as e:          # the primary line must still be printed ...
+            if world > 1:               # ... but never by leaving the other ranks blocked inside a collective
+                raise
             sec = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
     inf = None
@@ -367,6 +367,8 @@ def main():
         try:
             inf = inference_l14(dev, rank, world)
         except Exception as e:
+            if world > 1:
+                raise
             inf = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
     if rank == 0:

@@ -10,9 +10,10 @@
  * Conventions
  *   - every function returns 0 on success; non-zero -> aim_last_error() (thread-local text);
  *   - all pointers are DEVICE pointers unless said otherwise; the caller owns all memory
- *     (no allocation, no mutable global state, no implicit synchronisation inside the library:
- *     every knob of a launch is an argument of that call, so two host threads may drive two
- *     streams through the library at once);
+ *     (no allocation, no implicit synchronisation and no state that outlives a call inside the
+ *     library -- the only statics are idempotent one-time initialisations (a kernel's dynamic-LDS
+ *     attribute, environment switches read once); every knob of a launch is an argument of that
+ *     call, so two host threads may drive two streams through the library at once);
  *   - `stream` is a hipStream_t passed as void*; launches are stream-ordered;
  *   - matrices are row-major; "bf16" is IEEE bfloat16 stored as uint16_t; "ld*" are row strides
  *     in ELEMENTS;
@@ -296,14 +297,16 @@ int aim_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, floa
  *   ce_topk  : CrossEntropyLoss hard-label path (mmaction/models/losses/cross_entropy_loss.py:78) + top-k accuracy
  *              (mmaction/core/evaluation/accuracy.py:90-109, numpy argsort tie order: a label is in the top k iff
  *              fewer than k classes score higher or tie with a larger index), all on the device:
- *              out3 = {mean_b(-log softmax(score)[label]), top1, top5} ; dscore[B, C] = (softmax - onehot) / B.
+ *              out3 = {mean over VALID b of -log softmax(score)[label], top1, top5} ; dscore[B, C] = (softmax - onehot) / n_valid.
+ *              A label outside [0, C) is ignored exactly like F.cross_entropy's ignore_index (-100): no loss term, a zero
+ *              dscore row, not counted in the CE mean (top1 / top5 keep the denominator B: such a sample is a miss).
  *              One workgroup per sample writes per-sample terms, the last pass sums them in sample order (no atomics).
  * ------------------------------------------------------------------------------------------ */
 int aim_head_fwd(const float* feat, const float* drop, const float* W, const float* bias, float* pooled, float* score,
                  int B, int T, int D, int C, void* stream);
 int aim_head_bwd(const float* dscore, const float* pooled, const float* drop, const float* W, float* dW, float* db,
                  float* dfeat, int B, int T, int D, int C, void* stream);
-int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* per_sample /* [B, 3] scratch */,
+int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* per_sample /* [B, 4] scratch */,
                 float* out3, int B, int C, int k2 /* second k of the accuracy pair, 5 */, void* stream);
 
 #ifdef __cplusplus

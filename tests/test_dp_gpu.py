@@ -56,7 +56,8 @@ def _worker(rank, world, port, q):
     losses["loss_cls"].backward()
     assert len(opt._buckets) == 2                    # layers 1 and 0 are early buckets of the flat buffer
     opt.all_reduce_grads()
-    assert opt.early_launches == 2 and not opt._works and not opt._reduced      # both started from inside backward
+    assert opt.early_launches == 2 and not opt._works      # both started from inside backward
+    assert sorted(opt._reduced)[0][0] == 0 and opt._summed   # ... and the whole buffer has been through the collective
     # the collective is a SUM; the mean's 1 / world is folded into aim_adamw_flat(grad_scale=)
     grad = (opt.flat_g.detach() / world).cpu().clone()
     opt.step()
@@ -66,6 +67,40 @@ def _worker(rank, world, port, q):
         model(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)["loss_cls"].backward()
         opt.all_reduce_grads()
     assert opt.early_launches == 2
+    # The reference's hook contract is `backward(); optimizer.step()` (mmaction/utils/optimizer.py:22-33): a step that is
+    # NOT preceded by all_reduce_grads() must still finish the pending buckets and reduce the rest -- same parameters, bit
+    # for bit, as the explicit order above.
+    model2 = _build()
+    broadcast_module(model2)
+    opt2 = build_optimizer(model2, dict(type='AdamW', lr=1e-2, weight_decay=0.05,
+                                        paramwise_cfg=dict(custom_keys={'ln_post': dict(decay_mult=0.)})))
+    opt2.zero_grad()
+    model2(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)["loss_cls"].backward()
+    assert opt2.early_launches == 2 and opt2._works and not opt2._summed      # two buckets in flight, nothing waited for
+    assert opt2.grad_scale == 1.0
+    opt2.step()
+    assert opt2._summed and not opt2._works and opt2.grad_scale == 1.0 / world
+    assert torch.equal(opt2.flat_p.detach().cpu(), after)
+    # a second backward after the reduction has started would add local gradients to summed buckets: loud, never silent
+    with pytest.raises(RuntimeError, match="no_sync"):
+        model2(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)["loss_cls"].backward()
+    # DistOptimizerHook (update_interval = 2): the first micro-step communicates nothing, the boundary one reduces once;
+    # clip_grad_norm_ sees the MEAN gradient
+    from aim_amd.dist import DistOptimizerHook
+
+    class _Runner:
+        pass
+    run = _Runner()
+    run.optimizer, run.iter = opt2, 0
+    hook = DistOptimizerHook(update_interval=2, grad_clip=dict(max_norm=1e9))
+    hook.before_run(run)
+    early0 = opt2.early_launches
+    for it in range(2):
+        run.iter = it
+        run.outputs = dict(loss=model2(imgs[sl].cuda(), label[sl].cuda(), return_loss=True)["loss_cls"])
+        hook.after_train_iter(run)
+        assert opt2.early_launches == early0 + (2 if it == 1 else 0)
+    assert opt2.step_count == 2 and float(opt2.flat_g.abs().max()) == 0.0       # stepped once more, then zero_grad
     q.put((rank, grad.numpy(), after.numpy()))      # by value: the worker exits before the parent reads
     dist.barrier()
     dist.destroy_process_group()
