@@ -863,8 +863,15 @@ class _BackboneFn(torch.autograd.Function):
             c = s["ctxs"][i]
             if "recompute" in c:        # checkpoint=True: rebuild this block's context from its saved input
                 c = c["recompute"](i, c["x_in"], True)[1]
+            recomputed = "recompute" in s["ctxs"][i]
             dxb = blk_bwd(dxb, c, frozen["blocks"][i], s["adp"][i], layer_grads[i], B, T, N, H, keep)
             s["ctxs"][i] = c = None
+            if recomputed:
+                # the detached weight-gradient stream's closures hold this block's tensors (~0.2 GB per ViT-B layer at 8
+                # clips) until it is joined: with checkpointing the join is per block, so the memory goes back now (the
+                # main stream is ordered behind the detached one before it can re-use the blocks)
+                _Fork.join_detached(dev)
+                keep.clear()
             if hook is not None:
                 # every kernel that accumulates into the gradients of layers >= i has been QUEUED (adapter weight
                 # gradients on the detached stream): the data-parallel optimizer may start reducing that slice of the
@@ -925,6 +932,17 @@ class ViT_CLIP(nn.Module):
         # fp8 e4m3 operands on the block-scaled MFMA; no-grad forwards only).  AIM_INFER_FP8=1 selects fp8 globally.
         self.inference_precision = 'fp8' if os.environ.get("AIM_INFER_FP8", "0") == "1" else 'bf16'
         self._cast_table = None
+        # 'bf16': the product (bf16 MFMA operands, hand-written backward).  'fp32': the reference-precision verification
+        # forward (fp32_path.py; no-grad only), held to the reference's own fp32 outputs at 1e-5.
+        self.precision = 'bf16'
+
+    def set_precision(self, precision: str):
+        """'bf16' (default) | 'fp32': arithmetic of the forward.  fp32 = f32-MFMA kernels with the reference's fp32
+        arithmetic (vit_clip.py:433-458), ~1/16 of the bf16 MFMA rate, forward-only."""
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        return self
 
     # ---- reference API ------------------------------------------------------------------------
     def init_weights(self, pretrained=None):
@@ -1106,5 +1124,12 @@ class ViT_CLIP(nn.Module):
         if x.dtype == torch.float16:
             x = x.float()
         x = x.contiguous()
+        if self.precision == 'fp32':
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self._trainable_list()):
+                raise RuntimeError("precision='fp32' is the forward-only reference-precision mode: call it under "
+                                   "torch.no_grad() (training runs the bf16 path)")
+            from .fp32_path import forward_f32
+            with torch.no_grad():
+                return forward_f32(self, x).unsqueeze(-1).unsqueeze(-1)
         y = _BackboneFn.apply(self, torch.is_grad_enabled(), x, *self._trainable_list())     # [B, D, T]
         return y.unsqueeze(-1).unsqueeze(-1)                          # BDTHW for I3D head (:456)

@@ -79,9 +79,15 @@ SIGNATURES = {
     "aim_head_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "aim_ce_topk": [P, P, P, P, P, I, I, I, P],
     "aim_cast_multi": [P, I, P],
+    "aim_gemm_f32": [POINTER(GemmArgs), I, I, P],
+    "aim_attn_fwd_f32": [P, P, I, I, I, P],
+    "aim_cls_attn_fwd_f32": [P, L, P, I, I, I, P],
+    "aim_lambda_f32": [P, I, P, P, I, P, P, I, I, I, F, P],
+    "aim_patchify_f32": [P, I, P, P, P, I, I, I, I, I, I, P],
+    "aim_embed_ln_f32": [P, P, P, P, P, P, P, I, I, I, I, F, P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load_library():

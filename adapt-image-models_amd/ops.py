@@ -483,3 +483,66 @@ class CastTable:
 
     def run(self):
         check(load_library().aim_cast_multi(self.table.data_ptr(), self.n, _stream()), "aim_cast_multi")
+
+
+# ---- reference-precision (fp32) forward path: include/aim_kernels.h, "Reference-precision" section ----------------------
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=None, resid=None, af=None, at=None,
+             vec=None, bt=None, ntok: int = 0, act: int = 0, n_split: int = 0, act2: int = 0, ldv: Optional[int] = None,
+             batch: int = 1, stride_a: int = 0, stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None,
+             K: Optional[int] = None, lda: Optional[int] = None, ldw: Optional[int] = None, ldo: Optional[int] = None):
+    """``out(f32) = epilogue(a @ w.T)`` with fp32 operands on the f32 MFMA; ``epi`` in (EPI_BF16 = linear, EPI_ACT, EPI_F32)."""
+    for n_, t_ in (("a", a), ("w", w), ("out", out), ("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
+        _chk(t_, F32, n_)
+    g = GemmArgs()
+    g.A, g.W = a.data_ptr(), w.data_ptr()
+    g.M = a.shape[0] if M is None else M
+    g.K = a.shape[1] if K is None else K
+    g.N = w.shape[0] if N is None else N
+    g.lda = a.stride(0) if lda is None else lda
+    g.ldw = w.stride(0) if ldw is None else ldw
+    g.strideA, g.strideW = stride_a, stride_w
+    g.bias, g.resid = _p(bias), _p(resid)
+    g.ldr = resid.stride(0) if resid is not None else 0
+    g.af, g.at, g.vec, g.bt = _p(af), _p(at), _p(vec), _p(bt)
+    g.ldv = (vec.stride(0) if ldv is None else ldv) if vec is not None else 0
+    g.ntok = ntok
+    g.out = out.data_ptr()
+    g.ldo = (out.stride(-2) if out.dim() >= 2 else g.N) if ldo is None else ldo
+    g.act, g.n_split, g.act2, g.scale = act, n_split, act2, 1.0
+    check(load_library().aim_gemm_f32(byref(g), epi, batch, _stream()), "aim_gemm_f32")
+    return out
+
+
+def attn_fwd_f32(qkv, out, BT, N, H):
+    _chk(qkv, F32, "qkv"); _chk(out, F32, "out")
+    check(load_library().aim_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), BT, N, H, _stream()), "aim_attn_fwd_f32")
+
+
+def cls_attn_fwd_f32(qkv, row_stride: int, out_cls, B, T, H):
+    _chk(qkv, F32, "qkv"); _chk(out_cls, F32, "out_cls")
+    check(load_library().aim_cls_attn_fwd_f32(qkv.data_ptr(), int(row_stride), out_cls.data_ptr(), B, T, H, _stream()),
+          "aim_cls_attn_fwd_f32")
+
+
+def lambda_f32(scores, qkv, kx, lam, one_minus, BT, N, D, scale):
+    for n_, t_ in (("scores", scores), ("qkv", qkv), ("kx", kx), ("lam", lam), ("one_minus", one_minus)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_lambda_f32(scores.data_ptr(), scores.stride(-2), qkv.data_ptr(), kx.data_ptr(), kx.stride(0),
+                                        lam.data_ptr(), _p(one_minus), BT, N, D, scale, _stream()), "aim_lambda_f32")
+
+
+def patchify_f32(imgs, A, B, T, H, W, p, Kp, mean3=None, std3=None):
+    if imgs.dtype not in (torch.float32, torch.uint8):
+        raise TypeError(f"patchify_f32: unsupported input dtype {imgs.dtype} (float32, uint8)")
+    if not imgs.is_cuda or not imgs.is_contiguous():
+        raise ValueError("patchify_f32: imgs must be a contiguous GPU tensor")
+    _chk(A, F32, "A"); _chk(mean3, F32, "mean3"); _chk(std3, F32, "std3")
+    check(load_library().aim_patchify_f32(imgs.data_ptr(), _IN_DTYPES[imgs.dtype], _p(mean3), _p(std3), A.data_ptr(), B, T, H, W,
+                                          p, Kp, _stream()), "aim_patchify_f32")
+
+
+def embed_ln_f32(tok, cls, pos, temporal, gamma, beta, x, B, T, N, D, eps=1e-5):
+    for n_, t_ in (("tok", tok), ("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("beta", beta), ("x", x)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_embed_ln_f32(tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), temporal.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), x.data_ptr(), B, T, N, D, eps, _stream()), "aim_embed_ln_f32")

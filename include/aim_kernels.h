@@ -32,7 +32,7 @@ extern "C" {
 
 typedef uint16_t aim_bf16;
 
-#define AIM_ABI_VERSION 3
+#define AIM_ABI_VERSION 4
 
 int aim_version(void);                /* == AIM_ABI_VERSION */
 const char* aim_last_error(void);     /* message of the last failing call on this thread */
@@ -308,6 +308,34 @@ int aim_head_bwd(const float* dscore, const float* pooled, const float* drop, co
                  float* dfeat, int B, int T, int D, int C, void* stream);
 int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* per_sample /* [B, 4] scratch */,
                 float* out3, int B, int C, int k2 /* second k of the accuracy pair, 5 */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reference-precision (fp32) forward path: `ViT_CLIP.set_precision('fp32')`, no-grad forwards only.  The product path
+ * computes on bf16 MFMA operands; these entry points compute the SAME block from fp32 operands with fp32 accumulation
+ * (v_mfma_f32_16x16x4_f32: exact f32 products, 1/16 of the bf16 rate), exact erf / exp, probabilities normalised before
+ * P V -- the arithmetic of the reference's un-autocast run (vit_clip.py:433-458), so the GPU output is held DIRECTLY to
+ * the reference's fixtures at 1e-5 (BASELINE north_star), with no bf16-emulating oracle in between.
+ *   gemm_f32       : C = A W^T with A, W, bias, resid, out all f32 (aim_gemm_args with float operands); epilogues
+ *                    AIM_EPI_BF16 (read: linear, out(f32) = rs * (acc + bias)), AIM_EPI_ACT (out(f32) = [rs *] act(acc + bias),
+ *                    n_split / act2 as above; nothing saved), AIM_EPI_F32; batch > 1 (linear only) writes item z at
+ *                    out + z * M * ldo.  K, lda, ldw multiples of 4.  replaces vit_clip.py:93-97,132-138,157,286,436.
+ *   attn_fwd_f32   : softmax(q k^T / 8) v per (frame, head) on the fused f32 qkv rows [BT*N, 3D]; out [BT*N, D].  :139-156
+ *   cls_attn_fwd_f32 : the same over the T class tokens of each clip (sequence T, batch B); qkv rows of the class tokens
+ *                    are `row_stride` floats apart (N * 3D in the fused buffer); out [B*T, D].  :220-229
+ *   lambda_f32     : scores [BT][N][lds] = RAW full-width q_i . k_j (a batched gemm_f32 of q against k); kx [BT, ldkx] the
+ *                    cross-attention's single key; lam = cw / (cw + ow) with ow = sum_ij exp(scale s_ij), cw = sum_i
+ *                    exp(scale q_i . kx), one shared max shift.  :149-151,184-186,272
+ *   patchify_f32 / embed_ln_f32 : aim_patchify / aim_embed_ln with an f32 patch matrix / f32 tokens (in_dtype 0 | 1).  :434-447
+ * ------------------------------------------------------------------------------------------ */
+int aim_gemm_f32(const aim_gemm_args* args, int epilogue, int batch, void* stream);
+int aim_attn_fwd_f32(const float* qkv, float* out, int BT, int N, int H, void* stream);
+int aim_cls_attn_fwd_f32(const float* qkv, int64_t row_stride, float* out_cls, int B, int T, int H, void* stream);
+int aim_lambda_f32(const float* scores, int lds, const float* qkv, const float* kx, int ldkx, float* lam,
+                   float* one_minus_lam, int BT, int N, int D, float scale, void* stream);
+int aim_patchify_f32(const void* imgs, int in_dtype, const float* mean3, const float* std3, float* A, int B, int T,
+                     int H, int W, int p, int Kp, void* stream);
+int aim_embed_ln_f32(const float* tok, const float* cls, const float* pos, const float* temporal, const float* gamma,
+                     const float* beta, float* x, int B, int T, int N, int D, float eps, void* stream);
 
 #ifdef __cplusplus
 }
