@@ -285,8 +285,9 @@ def test_cfg4_full_shape_three_views():
     _record("cfg4_full_shape", **vals)
     # bf16 product vs reference-precision arithmetic through 24 blocks: the 24-layer noise floor of DESIGN.md section 5
     # (3.4e-3 against the bf16-rounding emulation) plus the emulation's own distance from fp32
-    assert vals["bf16_vs_fp32"] < 1.5e-2, vals
+    # (measured: bf16 5.0e-3, fp8 7.1e-2 from fp32; probabilities 4.8e-4 / 5.5e-3; both top-1 equal to fp32's)
+    assert vals["bf16_vs_fp32"] < 1e-2, vals
     # fp8: e4m3 has 2^-4 relative resolution against bf16's 2^-9; same bound form as the 2-layer oracle test, from fp32
-    assert vals["fp8_vs_fp32"] < 0.25 and vals["fp8_vs_bf16"] < 0.25, vals
-    assert vals["prob_bf16_vs_fp32"] < 2e-3 and vals["prob_fp8_vs_fp32"] < 2e-2, vals
+    assert vals["fp8_vs_fp32"] < 0.15 and vals["fp8_vs_bf16"] < 0.15, vals
+    assert vals["prob_bf16_vs_fp32"] < 1e-3 and vals["prob_fp8_vs_fp32"] < 1.2e-2, vals
     assert peak16 < 24 * 2 ** 30, peak16          # no-grad forwards keep no per-block context (3 views x 8 224 rows x 24 blocks)
