@@ -262,6 +262,7 @@ _AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0" and os.environ.get("AIM_G
 # workgroups) and the LayerNorm backward kernels are short workgroups that free CUs continuously, while a reservation costs
 # every N = 768 GEMM a whole tile round (1 182 tiles: 5 rounds on 256 CUs, 6 on 224: +20 %).  Unmeasured on > 1 GPU.
 _DP_RESERVE = int(os.environ.get("AIM_DP_RESERVE_CUS", "0"))
+_EXPSUM_BORDER = os.environ.get("AIM_EXPSUM_BORDER", "1") != "0"      # N = 257: one 256 x 256 tile per frame + aim_qk_border
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
 
@@ -510,18 +511,29 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
         ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
                  stride_w=N * 3 * D, scale=0.125, xrow=kv)
     else:
+        # N = 257 (ViT-L/14): the scores of tokens 0..255 against each other are ONE full tile per frame of the persistent
+        # 256 x 256 kernel (8 slots); the 257th row and column and the cross scores come from one pass over q and k
+        # (aim_qk_border: slots 8, 9).  Other N > 256 or N <= 128: the 128 x 128 kernel's tiles + qk_cross.
+        border = _EXPSUM_BORDER and N == 257 and D in (512, 1024) and _LAMBDA_ON_SIDE and _CLS_EARLY
+        nt = 10 if border else ops.expsum_tiles(N, N)
+        part = _empty((BT, nt, 2), F32, dev)
         # the cross scores q_i . kx (one pass over q) go to the side stream as soon as q exists, beside the ow GEMM
         if _LAMBDA_ON_SIDE and _CLS_EARLY:
             fork.sync_side_to_main()
             with fork.side():
                 ss = ar.take((BT, N), F32)
-                ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
-        nt = ops.expsum_tiles(N, N)
-        part = _empty((BT, nt, 2), F32, dev)
+                if border:
+                    ops.qk_border(qkv, kv, ss, part, 8, BT, N, D, 0.125)
+                else:
+                    ops.qk_cross(qkv, kv, ss, BT, N, D, 0.125)
 
         def expsum():
-            ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
-                     stride_w=N * 3 * D, scale=0.125)
+            if border:
+                ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N - 1, N=N - 1, K=D, batch=BT, stride_a=N * 3 * D,
+                         stride_w=N * 3 * D, scale=0.125, slot_stride=2 * nt)
+            else:
+                ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D,
+                         stride_w=N * 3 * D, scale=0.125)
 
         part_ready = fork.run_beside(expsum) if _EXPSUM_DETACHED else expsum()
 

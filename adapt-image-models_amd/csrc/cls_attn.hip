@@ -136,6 +136,84 @@ __global__ __launch_bounds__(256) void qk_cross_kernel(const bf16_t* __restrict_
     }
 }
 
+// lamda statistics of a frame whose token count is ONE more than the 256-row tile of the persistent GEMM (ViT-L/14: N = 257).
+// The 256 x 256 block of scores q_i . k_j (i, j < N - 1) runs as ONE full tile per frame on the large-tile EXPSUM kernel; this
+// kernel adds the border in one pass over q and one over k (two workgroups per frame):
+//   y = 0 (q pass): ss[i] = scale q_i . kx for every i (the cross scores, as qk_cross) and the (max, sum exp) of
+//                   scale q_i . k_{N-1}, i < N - 1  -> slot0;
+//   y = 1 (k pass): (max, sum exp) of scale q_{N-1} . k_j, j < N  -> slot0 + 1.
+// Eight rows per wave are in flight at a time (the one-row-at-a-time qk_cross is latency-bound: 143 us for 270 MB).
+__global__ __launch_bounds__(256) void qk_border_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx, int ldkx,
+                                                        float* __restrict__ ssg, float* __restrict__ part, int slot0, int nslots,
+                                                        int N, int D, float scale) {
+    __shared__ float sc[320];
+    __shared__ float red[8];
+    const int bt = blockIdx.x, pass = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = 3 * D, nch = D >> 9;          // 512-element chunks per row (D = 512 c: 1 | 2)
+    const bf16_t* frame = qkv + (long long)bt * N * ld;
+    // the fixed vectors of this pass: v0 = k_{N-1} (q pass) | q_{N-1} (k pass); v1 = kx (q pass only)
+    const bf16_t* p0 = frame + (long long)(N - 1) * ld + (pass == 0 ? D : 0);
+    const bf16_t* p1 = kx + (long long)bt * ldkx;
+    bf16x8 v0[2], v1[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        v0[c] = v1[c] = bf16x8{};
+        if (c < nch) {
+            v0[c] = *(const bf16x8*)(p0 + c * 512 + lane * 8);
+            if (pass == 0) v1[c] = *(const bf16x8*)(p1 + c * 512 + lane * 8);
+        }
+    }
+    const bf16_t* rows = frame + (pass == 0 ? 0 : D);          // q rows | k rows
+    const int nrow = N;
+    for (int i0 = wave * 8; i0 < nrow; i0 += 32) {
+        bf16x8 x[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int i = min(i0 + r, nrow - 1);
+                x[r][c] = c < nch ? *(const bf16x8*)(rows + (long long)i * ld + c * 512 + lane * 8) : bf16x8{};
+            }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = (float)x[r][c][e];
+                    a0 = fmaf(xv, (float)v0[c][e], a0);
+                    a1 = fmaf(xv, (float)v1[c][e], a1);
+                }
+            a0 = wave_sum(a0);
+            if (pass == 0) a1 = wave_sum(a1);
+            const int i = i0 + r;
+            if (lane == 0 && i < nrow) {
+                sc[i] = a0 * scale;
+                if (pass == 0) ssg[(long long)bt * N + i] = a1 * scale;
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = pass == 0 ? N - 1 : N;       // (the corner q_{N-1} . k_{N-1} belongs to the k pass)
+    float mx = -INFINITY;
+    for (int i = tid; i < cnt; i += 256) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sm = 0.f;
+    for (int i = tid; i < cnt; i += 256) sm += expf(sc[i] - mx);
+    sm = wave_sum(sm);
+    if (lane == 0) red[4 + wave] = sm;
+    __syncthreads();
+    if (tid == 0) {
+        float* po = part + ((long long)bt * nslots + slot0 + pass) * 2;
+        po[0] = mx;
+        po[1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
 // one block (4 waves) per frame; ssg == nullptr: compute the cross scores here (one-call form)
 __global__ __launch_bounds__(256) void lambda_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kx,
                                                      int ldkx, const float* __restrict__ ssg,
@@ -246,6 +324,17 @@ extern "C" int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, f
     hipLaunchKernelGGL(qk_cross_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)kx,
                        ldkx, ss, N, D, scale);
     AIM_CHECK_LAUNCH("aim_qk_cross");
+    return 0;
+}
+
+extern "C" int aim_qk_border(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, float* partials, int slot0, int nslots,
+                             int BT, int N, int D, float scale, void* stream) {
+    AIM_CHECK_ARG(BT > 0 && N > 1 && N <= 320 && (D == 512 || D == 1024) && ldkx >= D && (ldkx % 8) == 0,
+                  "qk_border: unsupported shape BT=%d N=%d D=%d (D = 512 | 1024, N <= 320)", BT, N, D);
+    AIM_CHECK_ARG(qkv && kx && ss && partials && slot0 >= 0 && slot0 + 2 <= nslots, "qk_border: bad arguments");
+    hipLaunchKernelGGL(qk_border_kernel, dim3(BT, 2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)kx, ldkx,
+                       ss, partials, slot0, nslots, N, D, scale);
+    AIM_CHECK_LAUNCH("aim_qk_border");
     return 0;
 }
 

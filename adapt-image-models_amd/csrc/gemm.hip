@@ -201,6 +201,7 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     }
     if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N) && (g.K % 64) == 0) {
         AIM_CHECK_ARG(!g.xrow || (g.N < 256 && (g.ldx % 8) == 0), "gemm: EXPSUM extra key needs N < 256 and ldx %% 8 == 0");
+        AIM_CHECK_ARG(g.ldo == 0 || g.ldo >= (g.xrow ? 32 : 16), "gemm: EXPSUM slot stride ldo=%d is smaller than the tile's own slots", g.ldo);
         return aim_gemm256_launch(g, epi, batch, st);
     }
     AIM_CHECK_ARG(!g.aux_frag, "gemm: aux_frag needs the large-tile kernel (ACT / DACT, batch 1, M >= 1024, N %% 8 == 0, K %% 64 == 0)");

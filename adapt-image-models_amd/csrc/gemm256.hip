@@ -379,9 +379,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int ntiles, in
         if (phase_skew && wm == 0) AIM_BAR();
         if (probe) { tp1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
         if constexpr (EPI == EPI_EXPSUM)
+            // (max, sum) slots of a tile: 8 (16 with an extra key) pairs; g.ldo > 0 sets the float stride between tiles, so a
+            //  caller can leave room for more slots behind them (aim_qk_border's)
             wave_expsum(g, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, lane,
                         (float*)g.out + ((long long)(cur.z * tiles_m1 + (cur.m0 >> 8)) * tiles_n + (cur.n0 >> 8)) *
-                                            (g.xrow ? 32 : 16) + wave * 2);
+                                            (g.ldo > 0 ? g.ldo : (g.xrow ? 32 : 16)) + wave * 2);
         else
             wave_epilogue<EPI, F8>(g, acc, escr + wave * EPI_SCRATCH, cur.m0 + wm * 128, cur.n0 + wn * 64, lane);
         if (probe) {        // diagnostics (aim_gemm_args.probe): per-tile timestamps of wave 0, 100 MHz ticks

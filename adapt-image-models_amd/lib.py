@@ -65,6 +65,7 @@ SIGNATURES = {
     "aim_lambda_partials": [P, P, P, I, P],
     "aim_qk_cross": [P, P, I, P, I, I, I, F, P],
     "aim_lambda": [P, P, I, P, P, I, P, P, I, I, I, F, P],
+    "aim_qk_border": [P, P, I, P, P, I, I, I, I, I, F, P],
     "aim_patchify": [P, I, P, P, P, I, I, I, I, I, I, P],
     "aim_embed_ln": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "aim_embed_bwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, P, L, P],

@@ -80,7 +80,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
          scale: float = 1.0, rs_bias_only: bool = False, batch: int = 1, stride_a: int = 0,
          stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None,
          lda: Optional[int] = None, ldw: Optional[int] = None, ldv: Optional[int] = None, n_split: int = 0,
-         act2: int = 0, xrow=None, reserve_cus: int = 0, probe=None, aux_grad: bool = False, aux_frag: bool = False):
+         act2: int = 0, xrow=None, reserve_cus: int = 0, probe=None, aux_grad: bool = False, aux_frag: bool = False,
+         slot_stride: int = 0):
     """``out = epilogue(a @ w.T)``; ``a`` is ``[M, K]`` (row stride ``lda``), ``w`` is ``[N, K]``."""
     lib = load_library()
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -103,7 +104,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=
     g.aux = _p(aux)
     g.ldaux = aux.stride(0) if aux is not None else 0
     g.out = out.data_ptr()
-    g.ldo = out.stride(0) if (out.dim() >= 2 and epi != EPI_EXPSUM) else 0
+    # EXPSUM: ldo = float stride between the (max, sum) slot groups of consecutive tiles (0: the tile's own 16 | 32)
+    g.ldo = (out.stride(0) if out.dim() >= 2 else 0) if epi != EPI_EXPSUM else int(slot_stride)
     g.out2 = _p(out2)
     g.ldo2 = out2.stride(0) if out2 is not None else 0
     g.scale, g.act, g.rs_bias_only = scale, act, int(rs_bias_only)
@@ -329,6 +331,14 @@ def qk_cross(qkv, kx, ss, BT, N, D, scale):
     _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(ss, F32, "ss")
     check(load_library().aim_qk_cross(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), ss.data_ptr(), BT, N, D, scale,
                                       _stream()), "aim_qk_cross")
+
+
+def qk_border(qkv, kx, ss, partials, slot0: int, BT, N, D, scale):
+    """Border of the lamda statistics for N = 257 (see aim_qk_border): fills ss [BT, N] and partials[:, slot0:slot0 + 2]."""
+    _chk(qkv, BF16, "qkv"); _chk(kx, BF16, "kx"); _chk(ss, F32, "ss"); _chk(partials, F32, "partials")
+    assert partials.dim() == 3 and partials.shape[0] == BT and partials.shape[2] == 2 and partials.is_contiguous()
+    check(load_library().aim_qk_border(qkv.data_ptr(), kx.data_ptr(), kx.stride(0), ss.data_ptr(), partials.data_ptr(), slot0,
+                                       partials.shape[1], BT, N, D, scale, _stream()), "aim_qk_border")
 
 
 def lambda_(qkv, kx, partials, ntiles, lam, one_minus, BT, N, D, scale, ss=None):

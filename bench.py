@@ -242,9 +242,15 @@ def main():
 
     if args.inference_only:
         print(json.dumps(inference_l14(dev, rank, world)), flush=True)
+        if os.environ.get("AIM_JOIN_STATS") and rank == 0:
+            from aim_amd import backbone as _bb
+            print("join stalls, ms per 12 steps (6 bf16 + 6 fp8):", {k: round(v, 3) for k, v in _bb.join_stats().items()}, file=sys.stderr)
         return
     if args.secondary_only:
         print(json.dumps(secondary_l14(dev, rank, world)), flush=True)
+        if os.environ.get("AIM_JOIN_STATS") and rank == 0:
+            from aim_amd import backbone as _bb
+            print("join stalls, ms per step:", {k: round(v / 4, 3) for k, v in _bb.join_stats().items()}, file=sys.stderr)
         return
     model = build_model(args.frames, dev)
     broadcast_module(model)

@@ -224,6 +224,13 @@ int aim_lambda_partials(const float* partials, float* lam, float* one_minus_lam,
 int aim_qk_cross(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, int BT, int N, int D, float scale, void* stream);
 int aim_lambda(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, const float* ss, const float* partials, int ntiles,
                float* lam, float* one_minus_lam, int BT, int N, int D, float scale, void* stream);
+/* lamda statistics when a frame has ONE token more than the large-tile GEMM's 256 rows (ViT-L/14, N = 257): the scores of tokens
+ * 0 .. N-2 against each other are one full 256 x 256 tile per frame of aim_gemm_bf16(AIM_EPI_EXPSUM, M = N = 256, 8 slots
+ * with a per-item slot stride of ldo floats); this adds the border -- (max, sum exp) of scale q_i . k_{N-1} (i < N-1) into
+ * partials[bt][slot0] and of scale q_{N-1} . k_j (j < N) into partials[bt][slot0 + 1] -- and the cross scores
+ * ss[bt][i] = scale q_i . kx[bt] in the same pass over q.  aim_lambda(ss, partials, nslots) finishes.  vit_clip.py:149-151,184-186 */
+int aim_qk_border(const aim_bf16* qkv, const aim_bf16* kx, int ldkx, float* ss, float* partials /* [BT, nslots, 2] */, int slot0,
+                  int nslots, int BT, int N, int D, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch embedding glue -- vit_clip.py:434-447.

@@ -416,6 +416,42 @@ def test_lambda():
     close(oml, 1 - ref, 1e-6, 1e-5, "1-lambda")
 
 
+@pytest.mark.parametrize("BT,D", [(5, 1024), (3, 512)])
+def test_lambda_border_form_n257(BT, D):
+    """ViT-L/14 (N = 257): one full 256 x 256 EXPSUM tile per frame + aim_qk_border (the 257th row / column and the cross
+    scores) against a float64 evaluation, and against the 3 x 3-tile form it replaces."""
+    ops = _ops()
+    N = 257
+    qkv = rnd((BT * N, 3 * D), 146, 0.3, torch.bfloat16)
+    kv = rnd((BT, 2 * D), 147, 0.4, torch.bfloat16)            # kx = the first D columns of the class chain's [k | v] rows
+    q, k = qkv[:, :D], qkv[:, D:2 * D]
+    part = torch.full((BT, 10, 2), float("nan"), device=DEV)
+    ops.gemm(qkv, qkv[:, D:], ops.EPI_EXPSUM, part, M=N - 1, N=N - 1, K=D, batch=BT, stride_a=N * 3 * D, stride_w=N * 3 * D,
+             scale=0.125, slot_stride=20)
+    ss = torch.full((BT, N), float("nan"), device=DEV)
+    ops.qk_border(qkv, kv, ss, part, 8, BT, N, D, 0.125)
+    lam, oml = torch.zeros(BT, device=DEV), torch.zeros(BT, device=DEV)
+    ops.lambda_(qkv, kv, part, 10, lam, oml, BT, N, D, 0.125, ss=ss)
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all() and torch.isfinite(ss).all()
+    qf, kf = q.float().reshape(BT, N, D).double().cpu(), k.float().reshape(BT, N, D).double().cpu()
+    kx = kv[:, :D].double().cpu()
+    s = qf @ kf.transpose(1, 2) * 0.125
+    c = (qf @ kx.unsqueeze(-1)).squeeze(-1) * 0.125
+    close(ss, c.float().to(DEV), 1e-4, 1e-5, "cross scores")
+    ow, cw = torch.exp(s).sum((1, 2)), torch.exp(c).sum(1)
+    ref = (cw / (cw + ow)).float().to(DEV)
+    close(lam, ref, 1e-7, 2e-4, "lamda (border form)")
+    close(oml, 1 - ref, 1e-6, 1e-5, "1 - lamda (border form)")
+    # the form it replaces: 3 x 3 tiles of 128 + qk_cross
+    nt = ops.expsum_tiles(N, N)
+    part9 = torch.zeros((BT, nt, 2), device=DEV)
+    ops.gemm(q, k, ops.EPI_EXPSUM, part9, M=N, N=N, K=D, batch=BT, stride_a=N * 3 * D, stride_w=N * 3 * D, scale=0.125)
+    lam9 = torch.zeros(BT, device=DEV)
+    ops.lambda_(qkv, kv, part9, nt, lam9, None, BT, N, D, 0.125)
+    close(lam, lam9, 1e-7, 1e-4, "border form vs tile form")
+
+
 # ------------------------------------------------------------------ wgrad ----------------------
 @pytest.mark.parametrize("M,Nw,Kw", [(64, 128, 128), (1000, 192, 768), (20, 32, 128), (4100, 768, 192), (512, 8, 16)])
 def test_wgrad(M, Nw, Kw):
