@@ -330,7 +330,7 @@ def main():
                 # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, profiles/)
                 traffic, traffic_src = None, None
                 mfma_busy = None
-                for name in ("r02_gemm_pmc.json", "r01_gemm_traffic.json"):
+                for name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_traffic.json"):
                     try:
                         tj = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["gemm256_kernel<%d>" % dom]
                         traffic = round(tj["hbm_bytes_per_launch"])

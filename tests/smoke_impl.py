@@ -29,4 +29,12 @@ def run_smoke():
     for n, gr in zip(names, grads):
         e = ((got[n].grad.cpu() - gr).norm() / (gr.norm() + 1e-30)).item()
         assert e < 2.5e-2, f"smoke grad mismatch {n}: {e}"
-    print(f"smoke ok: fwd rel err {rel:.2e}, max err {err:.2e}")
+    # the reference-precision mode (csrc/fp32.hip) against the oracle's literal fp32 restatement of vit_clip.py:433-458
+    # (itself pinned to the reference's fixtures): north_star's 1e-5 bar, max |a - b| / max |b|
+    with torch.no_grad():
+        y32 = m.set_precision('fp32')(imgs.to("cuda:0")).cpu()
+        ref32 = O.ref_backbone(imgs, {k: v.detach() for k, v in st.items()}, H, T)
+    m.set_precision('bf16')
+    e32 = ((y32 - ref32).abs().max() / ref32.abs().max()).item()
+    assert e32 <= 1e-5, f"smoke fp32 mismatch: {e32}"
+    print(f"smoke ok: bf16 fwd rel err {rel:.2e}, max err {err:.2e}; fp32 mode max-rel err {e32:.2e}")
