@@ -168,6 +168,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #ifndef AIM_STORE_POLICY
 #define AIM_STORE_POLICY 2
 #endif
+#ifndef AIM_ACT8_MFMA_LAYOUT
+#define AIM_ACT8_MFMA_LAYOUT 1       // 0: the fp8-output epilogue through the fp32 scratch (A/B builds)
+#endif
 #ifndef AIM_LOAD_POLICY
 #define AIM_LOAD_POLICY 0
 #endif
@@ -429,6 +432,77 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             if (allq) run16(std::true_type{}, std::true_type{}); else run16(std::true_type{}, std::false_type{});
         } else {
             if (allq) run16(std::false_type{}, std::true_type{}); else run16(std::false_type{}, std::false_type{});
+        }
+    } else if constexpr (EPI == EPI_ACT8 && AIM_ACT8_MFMA_LAYOUT) {
+        // fp8 output (inference: the [c_fc | D_fc1] GEMM) in the MFMA layout, like the bf16 outputs above: scale, bias, activation,
+        // row factor, the saturating cast and the packing of a lane's four columns into ONE dword happen on the accumulators,
+        // and a 16-row x 64-byte tile of fp8 crosses the scratch per sub-pass -- every lane writes four dwords, reads sixteen
+        // bytes of one row and stores them (four lanes per row, 16 rows per instruction).  The fp32-scratch form below moved
+        // 4x the LDS bytes in twice as many round trips per row (measured on the ViT-L/14 c_fc GEMM, M = 98 688, N = 4 352,
+        // K = 1 024: DESIGN.md, fp8 inference).  N and ldo in multiples of 16: sixteen-byte stores; in multiples of 8 only
+        // (checked by the launcher): two eight-byte stores of eight rows each.
+        const bool wide = ((g.N | g.ldo) & 15) == 0;
+        const int rr = wide ? lane >> 2 : lane >> 3, cc = wide ? (lane & 3) * 16 : (lane & 7) * 8;     // the lane's row / first column
+        const __amdgpu_buffer_rsrc_t rOut = epi_rsrc(g.out, (long long)m_base * g.ldo + n_base, (long long)rows_left * g.ldo);
+        f32x4 bj[4], wsj[4];
+        bool qg[4], rson[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = j * 16 + fq * 4;
+            const unsigned vb = cj < cols_left ? (unsigned)cj * 4u : AIM_OOB;
+            bj[j] = buf_load_f4(rBias, vb);
+            wsj[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (WS) wsj[j] = buf_load_f4(epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff), vb);
+            qg[j] = col_act(g, n_base + cj) == ACT_QGELU;
+            rson[j] = g.n_split == 0 || n_base + cj >= g.n_split;
+        }
+        constexpr int RS8 = 80;                                   // scratch row stride: 64 fp8 + 16 B pad
+        unsigned voO = cc < cols_left ? (unsigned)(rr * g.ldo + cc) : AIM_OOB;
+        const unsigned stO = (unsigned)g.ldo * (wide ? 16u : 8u);  // rows per store instruction
+        AIM_LDS char* wr = scr + frow * RS8 + fq * 4;             // + j * 16: the lane's 4 columns of tile j
+        const AIM_LDS char* rd = scr + rr * RS8 + cc;
+        auto run8m = [&](auto ROWF, auto ALLQ) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float rs = 1.0f;
+                if constexpr (decltype(ROWF)::value) rs = rowfac[(i * 16 + frow) * 2];
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float rsj = rson[j] ? rs : 1.0f;
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v;
+                        if constexpr (WS) v = acc[i][j][e] * wsj[j][e] + bj[j][e];
+                        else v = acc[i][j][e] + bj[j][e];
+                        y[e] = rsj * ((decltype(ALLQ)::value || qg[j]) ? quick_gelu(v) : gelu_erf(v));
+                    }
+                    w[j] = pack4_fp8(y[0], y[1], y[2], y[3]);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(AIM_LDS unsigned*)(wr + j * 16) = w[j];
+                asm volatile("" ::: "memory");
+                if (wide) {
+                    const u32x4 x = *(const AIM_LDS u32x4*)rd;
+                    buf_store16(rOut, voO, x);
+                    epi_advance(voO, stO);
+                } else {
+                    const u32x2 x0 = *(const AIM_LDS u32x2*)rd;
+                    const u32x2 x1 = *(const AIM_LDS u32x2*)(rd + 8 * RS8);
+                    __builtin_amdgcn_raw_buffer_store_b64(x0, rOut, voO, 0, AIM_STORE_POLICY);
+                    epi_advance(voO, stO);
+                    __builtin_amdgcn_raw_buffer_store_b64(x1, rOut, voO, 0, AIM_STORE_POLICY);
+                    epi_advance(voO, stO);
+                }
+            }
+        };
+        const bool allq = __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
+        if (rowf) {
+            if (allq) run8m(std::true_type{}, std::true_type{}); else run8m(std::true_type{}, std::false_type{});
+        } else {
+            if (allq) run8m(std::false_type{}, std::true_type{}); else run8m(std::false_type{}, std::false_type{});
         }
     } else if constexpr (EPI != EPI_F32) {
         // fp8 output (ACT8; the fp32-scratch form, which also still serves as the reference for the branch above): 8 lanes x 8 columns per row, 8 rows per wave-instruction, so every
