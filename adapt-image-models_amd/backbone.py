@@ -262,6 +262,7 @@ _AUX_FRAG = os.environ.get("AIM_AUX_FRAG", "1") != "0" and os.environ.get("AIM_G
 # workgroups) and the LayerNorm backward kernels are short workgroups that free CUs continuously, while a reservation costs
 # every N = 768 GEMM a whole tile round (1 182 tiles: 5 rounds on 256 CUs, 6 on 224: +20 %).  Unmeasured on > 1 GPU.
 _DP_RESERVE = int(os.environ.get("AIM_DP_RESERVE_CUS", "0"))
+_FP8_RES16 = os.environ.get("AIM_FP8_RES16", "1") != "0"      # fp8 inference: bf16 residual stream (0: fp32, the A/B form)
 _EXPSUM_BORDER = os.environ.get("AIM_EXPSUM_BORDER", "1") != "0"      # N = 257: one 256 x 256 tile per frame + aim_qk_border
 _QKV_RESERVE = int(os.environ.get("AIM_QKV_RESERVE", "32"))     # CUs the forward QKV GEMM leaves to the class-token chain (measured: 0/8/16 equal, 32 +0.7 %, 48 equal)
 
@@ -477,8 +478,11 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     if _CLS_EARLY:
         with fork.side():
             xl_cls = ar.take((BT, D), BF16)
-            ops.layernorm_fwd(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls, mean=ar.take((BT,), F32),
-                              rstd=ar.take((BT,), F32))
+            if x.dtype == BF16:      # (the fp8 path's residual stream is bf16)
+                ops.layernorm_fwd_x16(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls)
+            else:
+                ops.layernorm_fwd(x, fz.g1, fz.b1, BT, D, N * D, y_bf16=xl_cls, mean=ar.take((BT,), F32),
+                                  rstd=ar.take((BT,), F32))
             qkv_cls = ar.take((BT, 3 * D), BF16)
             ops.gemm(xl_cls, fz.Wqkv, ops.EPI_BF16, qkv_cls, bias=fz.bqkv)
             probs, ta, t_pre, t_h, kv, crs = cls_chain(qkv_cls, 1)      # "N = 1": the rows ARE the class tokens
@@ -488,7 +492,10 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
     if f8 is not None:
         xl = _empty((M, D), ops.FP8, dev)
         mean1 = rstd1 = None
-        ops.layernorm_fwd_fp8(x, fz.g1, fz.b1, M, D, D, xl)
+        if x.dtype == BF16:
+            ops.layernorm_fwd_x16(x, fz.g1, fz.b1, M, D, D, y8=xl)
+        else:
+            ops.layernorm_fwd_fp8(x, fz.g1, fz.b1, M, D, D, xl)
         ops.gemm_fp8(xl, f8.Wqkv, f8.sqkv, ops.EPI_BF16, qkv, bias=fz.bqkv, reserve_cus=reserve)
     else:
         xl = _empty((M, D), BF16, dev)
@@ -568,18 +575,27 @@ def _block_forward(x, fz: _Frozen, adp: Dict[str, _AdapterW], B, T, N, H, dms1, 
             torch.cuda.current_stream(dev).wait_event(part_ready)
         lam, oml, sin, sv, s_pre, s_h = lamda_chain()
     # x1 = x + (1 - lamda) * out_proj(ao) + drop_path(scale * s_vec)
-    x1 = _empty((M, D), F32, dev)
     H4 = 4 * D
     if f8 is not None:
-        ops.gemm_fp8(ao, f8.Wo, f8.so, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
+        # the residual stream of the fp8 path is bf16 (AIM_EPI_RES16: resid + update rounded once per update): against fp8
+        # GEMM operands (2^-4 relative) a 2^-9 rounding of the stream is noise, and the two residual GEMMs of a block move half
+        # the bytes of the fp32 form (they are store-bound at K = 1024)
+        r16 = x.dtype == BF16
+        epi_res, rdt = (ops.EPI_RES16, BF16) if r16 else (ops.EPI_F32, F32)
+        x1 = _empty((M, D), rdt, dev)
+        ops.gemm_fp8(ao, f8.Wo, f8.so, epi_res, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
         xn = _empty((M, D), ops.FP8, dev)
-        ops.layernorm_fwd_fp8(x1, fz.g2, fz.b2, M, D, D, xn)
+        if r16:
+            ops.layernorm_fwd_x16(x1, fz.g2, fz.b2, M, D, D, y8=xn)
+        else:
+            ops.layernorm_fwd_fp8(x1, fz.g2, fz.b2, M, D, D, xn)
         hcat = _empty((M, H4 + r), ops.FP8, dev)
         ops.gemm_fp8(xn, f8.Wcat1, f8.s1, ops.EPI_ACT8, hcat, bias=fz.bcat1, act=ops.ACT_QGELU, n_split=H4,
                      act2=ops.ACT_GELU, at=dms2, ntok=N)
-        x2 = _empty((M, D), F32, dev)
-        ops.gemm_fp8(hcat, f8.Wcat2, f8.s2, ops.EPI_F32, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
+        x2 = _empty((M, D), rdt, dev)
+        ops.gemm_fp8(hcat, f8.Wcat2, f8.s2, epi_res, x2, bias=fz.bpr, resid=x1, vec=fz.b2row, ldv=0, bt=dms2, ntok=N)
         return x2, None
+    x1 = _empty((M, D), F32, dev)
     ops.gemm(ao, fz.Wo, ops.EPI_F32, x1, bias=fz.bo, resid=x, af=oml, vec=sv, bt=dms1, ntok=N)
     x2, xn, mean2, rstd2, hcat_pre, a_s = _mlp_adapter_forward(x1, fz, dms2, N, save)
     ctx = None
@@ -810,6 +826,10 @@ class _BackboneFn(torch.autograd.Function):
             return _block_forward(x_in, frozen["blocks"][i], adp[i], B, T, N, H, dms1, dms2, save,
                                   f8=None if f8 is None else f8[i])
 
+        if f8 is not None and _FP8_RES16:            # the fp8 path's residual stream is bf16
+            x16 = _empty((M, D), BF16, dev)
+            ops.cast_bf16(x, x16)
+            x = x16
         for i in range(L):
             x_in = x
             x, c = run_block(i, x_in, need_grad and not ckpt)
@@ -818,7 +838,10 @@ class _BackboneFn(torch.autograd.Function):
         gw, gb = lnp_w.detach().float().contiguous(), lnp_b.detach().float().contiguous()
         y = _empty((BT, D), F32, dev)
         meanp, rstdp = _empty((BT,), F32, dev), _empty((BT,), F32, dev)
-        ops.layernorm_fwd(x, gw, gb, BT, D, N * D, y_f32=y, mean=meanp, rstd=rstdp)
+        if x.dtype == BF16:
+            ops.layernorm_fwd_x16(x, gw, gb, BT, D, N * D, y_f32=y)
+        else:
+            ops.layernorm_fwd(x, gw, gb, BT, D, N * D, y_f32=y, mean=meanp, rstd=rstdp)
         if need_grad:
             ctx.model, ctx.dims = model, (B, T, N, H, D, L)
             ctx.saved = dict(ctxs=ctxs, adp=adp, tok=tok, mean0=mean0, rstd0=rstd0, tmp=tmp, xL=x, gw=gw, meanp=meanp,

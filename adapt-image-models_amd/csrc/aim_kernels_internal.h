@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 typedef aim_gemm_args GemmArgs;
-enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, EPI_F32 = AIM_EPI_F32, EPI_EXPSUM = AIM_EPI_EXPSUM, EPI_ACT8 = AIM_EPI_ACT8 };
+enum { EPI_BF16 = AIM_EPI_BF16, EPI_ACT = AIM_EPI_ACT, EPI_DACT = AIM_EPI_DACT, EPI_F32 = AIM_EPI_F32, EPI_EXPSUM = AIM_EPI_EXPSUM, EPI_ACT8 = AIM_EPI_ACT8, EPI_RES16 = AIM_EPI_RES16 };
 enum { ACT_QGELU = AIM_ACT_QGELU, ACT_GELU = AIM_ACT_GELU };
 
 // CUs of the current device (per-call query, no cache; CU-masked caller streams are not supported: capi.hip).  Persistent

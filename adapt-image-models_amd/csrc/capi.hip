@@ -45,6 +45,8 @@ extern "C" int aim_gemm_fp8(const aim_gemm_args* args, int epilogue, void* strea
     AIM_CHECK_ARG((g.N % 8) == 0 && (g.n_split % 8) == 0 && (g.ldo % 8) == 0, "gemm_fp8: N, n_split and ldo must be multiples of 8");
     AIM_CHECK_ARG((((g.K + 127) / 128) & 1) == 0, "gemm_fp8: ceil(K / 128) must be even (K=%d)", g.K);
     AIM_CHECK_ARG(g.A && g.W && g.out && !g.xrow, "gemm_fp8: null operand / unsupported xrow");
+    if (epilogue == EPI_RES16)
+        AIM_CHECK_ARG(g.resid && (g.ldr % 8) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128), "gemm_fp8: RES16 needs a bf16 residual (ldr %% 8 == 0) and ntok >= 128 with vec");
     if (epilogue == EPI_F32) AIM_CHECK_ARG((g.ldr % 4) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128), "gemm_fp8: F32 epilogue strides");
     if (g.af || g.at || g.vec) AIM_CHECK_ARG(g.ntok > 0, "gemm_fp8: ntok required with row factors");
     return aim_gemm256_fp8_launch(g, epilogue, (hipStream_t)stream);

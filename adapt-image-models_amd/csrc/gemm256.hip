@@ -447,8 +447,9 @@ int aim_gemm256_fp8_launch(const GemmArgs& g, int epi, hipStream_t st) {
         case EPI_BF16: return launch256<EPI_BF16, true>(g, 1, st);
         case EPI_F32: return launch256<EPI_F32, true>(g, 1, st);
         case EPI_ACT8: return launch256<EPI_ACT8, true>(g, 1, st);
+        case EPI_RES16: return launch256<EPI_RES16, true>(g, 1, st);
     }
-    aim_set_error("gemm_fp8: unsupported epilogue %d (BF16, F32, ACT8)", epi);
+    aim_set_error("gemm_fp8: unsupported epilogue %d (BF16, F32, ACT8, RES16)", epi);
     return 1;
 }
 

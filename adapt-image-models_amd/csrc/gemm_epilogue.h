@@ -160,7 +160,8 @@ __device__ __forceinline__ void store_frag8(const GemmArgs& g, f32x4 v0, f32x4 v
 constexpr int EPI_RS = 272;                      // scratch row stride: 64 f32 + 16 B pad (8-row fp32 sub-passes)
 constexpr int EPI_RSH = 144;                     // scratch row stride: 64 bf16 + 16 B pad (16-row bf16 sub-passes)
 constexpr int EPI_ROWFAC = 16 * EPI_RSH;         // offset of the per-row factor table: 128 rows x {rs, vs}  (>= 8 * EPI_RS)
-constexpr int EPI_SCRATCH = EPI_ROWFAC + 128 * 8;   // bytes per wave (fits beside the K-loop images)
+constexpr int EPI_VEC = EPI_ROWFAC + 128 * 8;    // offset of the two candidate `vec` rows of the wave tile (RES16): 2 x 64 f32
+constexpr int EPI_SCRATCH = EPI_VEC + 2 * 64 * 4;   // bytes per wave (fits beside the K-loop images)
 static_assert(16 * EPI_RSH >= 8 * EPI_RS, "the fp32 sub-pass scratch must fit in front of the row-factor table");
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -259,7 +260,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         }
     }
 
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_ACT || EPI == EPI_DACT) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_ACT || EPI == EPI_DACT || EPI == EPI_RES16) {
         // bf16 outputs without a second input (BF16, ACT): bias, row factor, activation and the cast to bf16 are applied in
         // the MFMA layout (lane = row frow, 4 consecutive columns per 16-column tile), and a whole 16-row tile of bf16 values
         // crosses the scratch at a time: every lane writes (no exec mask), half the LDS bytes of the fp32 sub-passes below and
@@ -273,10 +274,32 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             epi_rsrc(g.out, ((long long)m_base * g.ldo + n_base) * 2, (long long)rows_left * g.ldo * 2);
         const __amdgpu_buffer_rsrc_t rOut2 = epi_rsrc(EPI == EPI_ACT ? g.out2 : nullptr,
                                                       ((long long)m_base * g.ldo2 + n_base) * 2, (long long)rows_left * g.ldo2 * 2);
-        const __amdgpu_buffer_rsrc_t rAux = epi_rsrc(EPI == EPI_DACT ? g.aux : nullptr,
-                                                     ((long long)m_base * g.ldaux + n_base) * 2, (long long)rows_left * g.ldaux * 2);
-        unsigned voA = ncol ? (unsigned)(r8 * g.ldaux + c8) * 2u : AIM_OOB;
-        const unsigned stA = (unsigned)g.ldaux * 16u;
+        // second input in row segments: DACT's saved rows (aux) | RES16's bf16 residual rows (resid, ldr)
+        constexpr bool ROWIN = EPI == EPI_DACT || EPI == EPI_RES16;
+        const int ldin = EPI == EPI_RES16 ? g.ldr : g.ldaux;
+        const __amdgpu_buffer_rsrc_t rAux = epi_rsrc(EPI == EPI_DACT ? g.aux : EPI == EPI_RES16 ? (const void*)g.resid : nullptr,
+                                                     ((long long)m_base * ldin + n_base) * 2, (long long)rows_left * ldin * 2);
+        unsigned voA = ncol ? (unsigned)(r8 * ldin + c8) * 2u : AIM_OOB;
+        const unsigned stA = (unsigned)ldin * 16u;
+        // RES16: the per-frame vector `vec` of the (at most two) frames this wave tile touches, 64 columns each, in the scratch
+        AIM_LDS float* vecs = (AIM_LDS float*)(scr + EPI_VEC);
+        int bnd = 1 << 30;            // first tile-local row that belongs to the second frame
+        if constexpr (EPI == EPI_RES16) {
+            if (g.vec) {
+                const int mcl = m_base < g.M ? m_base : g.M - 1;
+                const int frame0 = mcl / g.ntok;
+                const int nframes = (g.M + g.ntok - 1) / g.ntok;
+                bnd = (frame0 + 1) * g.ntok - m_base;
+                const __amdgpu_buffer_rsrc_t rVec = epi_rsrc(g.vec, (long long)n_base * 4, 0x7fffffff);
+                const bool in = lane < cols_left;
+                vecs[lane] = buf_load_f1(rVec, in ? (unsigned)(frame0 * g.ldv + lane) * 4u : AIM_OOB);
+                vecs[64 + lane] = buf_load_f1(rVec, (in && frame0 + 1 < nframes) ? (unsigned)((frame0 + 1) * g.ldv + lane) * 4u : AIM_OOB);
+            } else {
+                vecs[lane] = 0.f;
+                vecs[64 + lane] = 0.f;
+            }
+            asm volatile("" ::: "memory");
+        }
         // aux_frag: out2 (ACT) / aux (DACT) is a FRAGMENT-ordered buffer private to this kernel pair -- [row tile][column tile]
         // [wave][16x16 tile i * 4 + j][lane] x 4 bf16, the lane's own accumulator elements, so neither side re-tiles it through
         // LDS: the forward stores 8 bytes per lane (512 contiguous bytes per instruction), the dgrad loads them back.  Both
@@ -302,7 +325,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             }
         };
         auto load_aux16 = [&](int slot) {
-            if constexpr (EPI == EPI_DACT) {
+            if constexpr (ROWIN) {
                 ax[slot][0] = buf_load_h8(rAux, voA);
                 epi_advance(voA, stA);
                 ax[slot][1] = buf_load_h8(rAux, voA);
@@ -319,7 +342,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             wsj[j] = f32x4{1.f, 1.f, 1.f, 1.f};
             if constexpr (WS) wsj[j] = buf_load_f4(epi_rsrc(g.wscale, (long long)n_base * 4, 0x7fffffff), vb);
             qg[j] = col_act(g, n_base + cj) == ACT_QGELU;
-            rson[j] = EPI == EPI_BF16 || g.n_split == 0 || n_base + cj >= g.n_split;       // (ACT / DACT: adapter columns only)
+            rson[j] = EPI == EPI_BF16 || EPI == EPI_RES16 || g.n_split == 0 || n_base + cj >= g.n_split;       // (ACT / DACT: adapter columns only)
         }
         unsigned voO = ncol ? (unsigned)(r8 * g.ldo + c8) * 2u : AIM_OOB;
         unsigned voO2 = ncol ? (unsigned)(r8 * g.ldo2 + c8) * 2u : AIM_OOB;
@@ -362,7 +385,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                         pre[j] = (j & 1) ? bf16x4{f8[4], f8[5], f8[6], f8[7]} : bf16x4{f8[0], f8[1], f8[2], f8[3]};
                     }
                     if (i + 3 < 8) load_frag16(i % 3, i + 3);
-                } else if constexpr (EPI == EPI_DACT) {       // this tile's pre-activations: row segments -> MFMA layout (pre[j])
+                } else if constexpr (ROWIN) {       // this tile's second input (saved rows | residual rows): row segments -> MFMA layout (pre[j])
                     asm volatile("" ::: "memory");
                     *(AIM_LDS bf16x8*)(scr + r8 * EPI_RSH + c8 * 2) = ax[i % 3][0];
                     *(AIM_LDS bf16x8*)(scr + (r8 + 8) * EPI_RSH + c8 * 2) = ax[i % 3][1];
@@ -382,6 +405,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                     const float rsj = rson[j] ? rs : 1.0f;
                     if constexpr (EPI == EPI_BF16) {
                         o[j] = pack4(rsj * v[0], rsj * v[1], rsj * v[2], rsj * v[3]);
+                    } else if constexpr (EPI == EPI_RES16) {
+                        // out = resid + rs (acc + bias) + bt[tok] vec[frame]: the F32 epilogue's sum on a bf16 residual stream
+                        const int rl = i * 16 + frow;
+                        const float vs = decltype(ROWF)::value ? rowfac[rl * 2 + 1] : 0.0f;
+                        const f32x4 vv = *(const AIM_LDS f32x4*)(vecs + (rl >= bnd ? 64 : 0) + j * 16 + fq * 4);
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = ((float)pre[j][e] + rsj * v[e]) + vs * vv[e];
+                        o[j] = pack4(y[0], y[1], y[2], y[3]);
                     } else if constexpr (EPI == EPI_DACT) {
                         if (g.aux_grad) {          // aux holds the activation's derivative already
                             const f32x2 y0 = (f32x2{v[0], v[1]} * rsj) * f32x2{(float)pre[j][0], (float)pre[j][1]};
@@ -427,7 +459,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
                 }
             }
         };
-        const bool allq = EPI != EPI_BF16 && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
+        const bool allq = EPI != EPI_BF16 && EPI != EPI_RES16 && __builtin_amdgcn_ballot_w64(qg[0] && qg[1] && qg[2] && qg[3]) == ~0ull;
         if (rowf) {
             if (allq) run16(std::true_type{}, std::true_type{}); else run16(std::true_type{}, std::false_type{});
         } else {

@@ -12,8 +12,19 @@ namespace {
 
 constexpr int MAXC = 8;  // float4 chunks per lane: D <= 8*4*64 = 2048 (template NC = chunks actually used)
 
-template <int NC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
+// (row elements as f32x4 from an fp32 or a bf16 row: the fp8 inference path keeps its residual stream in bf16)
+template <typename TX>
+__device__ __forceinline__ f32x4 ln_load4(const TX* p) {
+    if constexpr (sizeof(TX) == 4) {
+        return *(const f32x4*)p;
+    } else {
+        const bf16x4 b = *(const bf16x4*)p;
+        return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    }
+}
+
+template <int NC, typename TX = float>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16_t* __restrict__ yb, float* __restrict__ yf, long long ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
@@ -22,14 +33,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int row = (int)AIM_REV_BLOCK * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 2;
-    const float* xr = x + (long long)row * ldx;
+    const TX* xr = x + (long long)row * ldx;
     f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nch) {
-            v[c] = *(const f32x4*)(xr + ch * 4);
+            v[c] = ln_load4(xr + ch * 4);
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
     }
@@ -243,6 +254,24 @@ extern "C" int aim_layernorm_fwd_fp8(const float* x, int64_t ldx, const float* g
     else if (nc == 4) AIM_LN_FWD8(4); else AIM_LN_FWD8(8);
 #undef AIM_LN_FWD8
     AIM_CHECK_LAUNCH("aim_layernorm_fwd_fp8");
+    return 0;
+}
+
+// bf16 rows in (the fp8 inference path's residual stream); y as bf16 and / or f32 and / or fp8
+extern "C" int aim_layernorm_fwd_x16(const aim_bf16* x, int64_t ldx, const float* gamma, const float* beta, aim_bf16* y_bf16,
+                                     float* y_f32, uint8_t* y_fp8, int64_t ldy, int rows, int D, float eps, void* stream) {
+    AIM_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0 && D <= MAXC * 256, "layernorm_fwd_x16: bad shape rows=%d D=%d", rows, D);
+    AIM_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32 || y_fp8), "layernorm_fwd_x16: null pointer");
+    AIM_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "layernorm_fwd_x16: strides must be multiples of 4");
+#define AIM_LN_FWDX(NC)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<NC, bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, \
+                       (long long)ldx, gamma, beta, (bf16_t*)y_bf16, y_f32, (long long)ldy, (float*)nullptr, (float*)nullptr, \
+                       rows, D, eps, y_fp8)
+    const int nc = (D + 255) / 256;
+    if (nc <= 1) AIM_LN_FWDX(1); else if (nc == 2) AIM_LN_FWDX(2); else if (nc == 3) AIM_LN_FWDX(3);
+    else if (nc == 4) AIM_LN_FWDX(4); else AIM_LN_FWDX(8);
+#undef AIM_LN_FWDX
+    AIM_CHECK_LAUNCH("aim_layernorm_fwd_x16");
     return 0;
 }
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "aim_wgrad_bias_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, P, L, P],
     "aim_layernorm_fwd": [P, L, P, P, P, P, L, P, P, I, I, F, P],
     "aim_layernorm_fwd_fp8": [P, L, P, P, P, L, I, I, F, P],
+    "aim_layernorm_fwd_x16": [P, L, P, P, P, P, P, L, I, I, F, P],
     "aim_layernorm_bwd": [P, I, L, P, L, P, P, P, P, I, P, P, L, P, P, I, I, P],
     "aim_layernorm_bwd_fsum": [P, L, P, L, P, P, P, P, P, L, P, P, I, I, I, I, P],
     "aim_attn_fwd": [P, P, P, I, I, I, P],

@@ -10,7 +10,7 @@ import torch
 
 from .lib import GemmArgs, check, load_library
 
-EPI_BF16, EPI_ACT, EPI_DACT, EPI_F32, EPI_EXPSUM, EPI_ACT8 = 0, 1, 2, 3, 4, 5
+EPI_BF16, EPI_ACT, EPI_DACT, EPI_F32, EPI_EXPSUM, EPI_ACT8, EPI_RES16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950); stored as bytes
 ACT_QGELU, ACT_GELU = 0, 1
 
@@ -149,8 +149,9 @@ def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, epi: int,
     for n_, t_ in (("a8", a8), ("w8", w8)):
         if not t_.is_cuda or t_.element_size() != 1 or t_.stride(-1) != 1:
             raise TypeError(f"{n_}: expected a GPU fp8 (1-byte) tensor with a contiguous last dimension")
-    for n_, t_ in (("wscale", wscale), ("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
+    for n_, t_ in (("wscale", wscale), ("bias", bias), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
         _chk(t_, F32, n_)
+    _chk(resid, BF16 if epi == EPI_RES16 else F32, "resid")       # RES16: the bf16 residual stream of the fp8 inference path
     g = GemmArgs()
     g.A, g.W = a8.data_ptr(), w8.data_ptr()
     g.M, g.K, g.N = a8.shape[0], a8.shape[1], w8.shape[0]
@@ -163,7 +164,7 @@ def gemm_fp8(a8: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, epi: int,
     g.out, g.ldo = out.data_ptr(), out.stride(0)
     g.act, g.n_split, g.act2, g.scale = act, n_split, act2, 1.0
     g.reserve_cus = int(reserve_cus)
-    if epi == EPI_BF16:
+    if epi in (EPI_BF16, EPI_RES16):
         _chk(out, BF16, "out")
     elif epi == EPI_F32:
         _chk(out, F32, "out")
@@ -198,6 +199,15 @@ def layernorm_fwd_fp8(x, gamma, beta, rows, D, ldx, y8, ldy=None, eps: float = 1
         raise TypeError("y8: expected a GPU fp8 (1-byte) tensor")
     check(load_library().aim_layernorm_fwd_fp8(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y8.data_ptr(),
                                                D if ldy is None else ldy, rows, D, eps, _stream()), "aim_layernorm_fwd_fp8")
+
+
+def layernorm_fwd_x16(x, gamma, beta, rows, D, ldx, *, y_bf16=None, y_f32=None, y8=None, ldy=None, eps: float = 1e-5):
+    """LayerNorm over bf16 rows (the fp8 inference path's residual stream); any subset of bf16 / f32 / fp8 outputs."""
+    _chk(x, BF16, "x"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta"); _chk(y_bf16, BF16, "y_bf16"); _chk(y_f32, F32, "y_f32")
+    if y8 is not None and (y8.element_size() != 1 or not y8.is_cuda):
+        raise TypeError("y8: expected a GPU fp8 (1-byte) tensor")
+    check(load_library().aim_layernorm_fwd_x16(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _p(y_bf16), _p(y_f32), _p(y8),
+                                               D if ldy is None else ldy, rows, D, eps, _stream()), "aim_layernorm_fwd_x16")
 
 
 def attn_fwd_fp8(qkv, out8, BT, N, H, lse=None):

@@ -54,8 +54,10 @@ enum {
                           (rs_bias_only != 0: out = resid + acc + rs*bias + ...)               */
     AIM_EPI_EXPSUM = 4,/* out(f32)[batch][tile][2] = (max, sum exp(scale*acc - max)) over the
                           valid part of each 128x128 tile (lambda statistics, :149-151)         */
-    AIM_EPI_ACT8 = 5   /* out(fp8 e4m3) = sat(rs * act(acc + bias)): inference only, nothing saved
+    AIM_EPI_ACT8 = 5,  /* out(fp8 e4m3) = sat(rs * act(acc + bias)): inference only, nothing saved
                           for a backward (aim_gemm_fp8)                                         */
+    AIM_EPI_RES16 = 6  /* out(bf16) = resid(bf16) + rs*(acc + bias) + bt[tok]*vec[frame][n]: AIM_EPI_F32's sum on
+                          a bf16 residual stream (fp8 inference only, aim_gemm_fp8; ldr in bf16 elements)    */
 };
 enum { AIM_ACT_QGELU = 0, AIM_ACT_GELU = 1 };
 
@@ -121,7 +123,7 @@ int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stre
  * block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate), fp32 accumulate.
  * Weights are quantised once per output channel (wscale[n] = amax_n / 448), activations are saturating casts made by
  * the producing kernel (aim_layernorm_fwd y_fp8, AIM_EPI_ACT8, aim_attn_fwd out_fp8).  Epilogues: AIM_EPI_BF16,
- * AIM_EPI_F32, AIM_EPI_ACT8.  Large-M problems only (M >= 1024, N >= 64, N % 8 == 0). */
+ * AIM_EPI_F32, AIM_EPI_ACT8, AIM_EPI_RES16.  Large-M problems only (M >= 1024, N >= 64, N % 8 == 0). */
 int aim_gemm_fp8(const aim_gemm_args* args, int epilogue, void* stream);
 /* number of (max,sum) pairs AIM_EPI_EXPSUM writes per batch entry */
 int aim_gemm_expsum_tiles(int M, int N);
@@ -157,6 +159,10 @@ int aim_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
 /* inference form: y as fp8 e4m3 bytes (saturating cast, row stride ldy bytes); no statistics are saved */
 int aim_layernorm_fwd_fp8(const float* x, int64_t ldx, const float* gamma, const float* beta, uint8_t* y_fp8,
                           int64_t ldy, int rows, int D, float eps, void* stream);
+/* the same LayerNorm over bf16 rows (the fp8 inference path keeps its residual stream in bf16: AIM_EPI_RES16);
+ * any subset of the three outputs */
+int aim_layernorm_fwd_x16(const aim_bf16* x, int64_t ldx, const float* gamma, const float* beta, aim_bf16* y_bf16,
+                          float* y_f32, uint8_t* y_fp8, int64_t ldy, int rows, int D, float eps, void* stream);
 int aim_layernorm_bwd(const void* dy, int dy_is_bf16 /* dy is bf16 (1) or f32 (0) */, int64_t lddy,
                       const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const void* dres, int dres_is_bf16, float* dx,

@@ -450,6 +450,8 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
     dm = 1.0 if d1 is None else d1.reshape(1, N, 1)
     dm2 = 1.0 if d2 is None else d2.reshape(1, N, 1)
     x1 = x + (1 - lam)[:, None, None] * proj + dm * scale * sv[:, None, :]
+    if f8:
+        x1 = rnd(x1)          # the fp8 inference path keeps its residual stream in bf16 (AIM_EPI_RES16: one rounding per update)
     # --- MLP + MLP_Adapter --------------------------------------------------------
     xn_f = F.layer_norm(x1, (D,), st[pre + "ln_2.weight"], st[pre + "ln_2.bias"], 1e-5)
     if f8:
@@ -459,7 +461,7 @@ def emu_block(x: Tensor, st: State, i: int, heads: int, T: int, scale: float,
         a = dm2 * scale * F.gelu(lin8(xn_f, st[ap + "D_fc1.weight"], st[ap + "D_fc1.bias"]))
         wcat2 = torch.cat([st[pre + "mlp.c_proj.weight"], st[ap + "D_fc2.weight"]], dim=1)
         out2 = lin8(torch.cat([h, a], dim=-1), wcat2, None)
-        x2 = x1 + out2 + st[pre + "mlp.c_proj.bias"] + dm2 * scale * st[ap + "D_fc2.bias"]
+        x2 = rnd(x1 + out2 + st[pre + "mlp.c_proj.bias"] + dm2 * scale * st[ap + "D_fc2.bias"])
         if return_aux:
             return x2, dict(lamda=lam, xt=xt, ow_shifted=ow, cw_shifted=cw, shift=m)
         return x2
@@ -559,6 +561,8 @@ def emu_backbone(imgs: Tensor, st: State, heads: int, scale: float = 0.5,
     if layers is None:
         layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("transformer.resblocks."))
     x = emu_embed(imgs, st, rnd)
+    if f8:
+        x = rnd(x)
     for i in range(layers):
         x = emu_block(x, st, i, heads, T, scale, rnd, drop_mask=None if drop_masks is None else drop_masks[i], f8=f8)
     c = F.layer_norm(x[:, 0], (x.shape[-1],), st["ln_post.weight"], st["ln_post.bias"], 1e-5)

@@ -76,6 +76,14 @@ def test_gemm_fp8_epilogues(M, N, K):
     else:
         want32 = resid + ref + bias
     assert _rel(out32, want32) < 1e-5, _rel(out32, want32)
+    # RES16: the same sum on a bf16 residual stream, rounded to bf16 once
+    resid16 = resid.to(torch.bfloat16)
+    out16 = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    kw16 = dict(kw, resid=resid16.to(DEV))
+    ops.gemm_fp8(a8, w8, ws.to(DEV), ops.EPI_RES16, out16, **kw16)
+    want16 = (want32 - resid + resid16.float())
+    assert _rel(out16, want16.to(torch.bfloat16)) < 2e-3
+    assert (out16.float().cpu() - want16).abs().max() <= 2 ** -7 * want16.abs().max()          # one bf16 rounding of the sum
     # ACT8 with a column split (QuickGELU | at * GELU) -> fp8 bytes
     ns = (N // 2) // 8 * 8
     at = torch.rand(ntok, generator=g) if ntok >= 128 else None
@@ -150,6 +158,24 @@ def test_fp8_producers_match_their_twins():
     got, want = o8.float().cpu(), O.q8(o16.float().cpu())
     # o8 is cast from the fp32 accumulators, o16 went through bf16 first: grid points may differ by one fp8 ulp
     assert (got == want).float().mean() > 0.97 and _rel(got, want) < 2e-2
+
+
+def test_layernorm_bf16_rows_in():
+    """aim_layernorm_fwd_x16 (the fp8 path's bf16 residual stream) against the fp32-input kernel on the same bf16 values."""
+    from aim_amd import ops
+    rows, D, N = 600, 1024, 3
+    x16 = (torch.randn((rows * N, D), generator=torch.Generator().manual_seed(9)) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    g_, b_ = torch.rand(D, device=DEV) + 0.5, torch.randn(D, device=DEV) * 0.1
+    ya, yb = torch.empty((rows, D), device=DEV), torch.empty((rows, D), device=DEV)
+    ops.layernorm_fwd_x16(x16, g_, b_, rows, D, N * D, y_f32=ya)                 # strided rows (class tokens)
+    ops.layernorm_fwd(x16.float(), g_, b_, rows, D, N * D, y_f32=yb)
+    assert torch.equal(ya, yb)
+    y8a = torch.empty((rows * N, D), dtype=torch.uint8, device=DEV)
+    y8b = torch.empty_like(y8a)
+    y16 = torch.empty((rows * N, D), dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd_x16(x16, g_, b_, rows * N, D, D, y8=y8a, y_bf16=y16)
+    ops.layernorm_fwd_fp8(x16.float(), g_, b_, rows * N, D, D, y8b)
+    assert torch.equal(y8a, y8b)
 
 
 def _model(res, T, patch, D, L, H, seed):
