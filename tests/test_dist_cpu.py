@@ -145,3 +145,58 @@ def test_lazy_log_vars_and_aim_registry_surface():
         aim_amd.AIM(32, 2, 16, 128, 2, 2, 0.1, num_tadapter=2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 2, 32, 32))
+
+
+def test_dist_optimizer_hook_micro_stepping():
+    """DistOptimizerHook (mmaction/utils/optimizer.py:9-33) on a recording optimizer: loss /= update_interval, backward on
+    every iteration -- inside no_sync() on the non-boundary ones --, clip + step + zero_grad on every update_interval-th."""
+    import contextlib
+
+    from aim_amd.dist import DistOptimizerHook
+
+    class Opt:
+        def __init__(self):
+            self.log, self.in_no_sync = [], False
+
+        @contextlib.contextmanager
+        def no_sync(self):
+            self.in_no_sync = True
+            try:
+                yield
+            finally:
+                self.in_no_sync = False
+
+        def zero_grad(self):
+            self.log.append("zero")
+
+        def step(self):
+            self.log.append("step")
+
+        def clip_grad_norm_(self, max_norm, norm_type=2.0):
+            self.log.append(("clip", max_norm))
+
+    class Loss:
+        def __init__(self, opt, v):
+            self.opt, self.v = opt, v
+
+        def __itruediv__(self, k):
+            self.v /= k
+            return self
+
+        def backward(self):
+            self.opt.log.append(("backward", self.v, self.opt.in_no_sync))
+
+    class Runner:
+        pass
+
+    opt = Opt()
+    run = Runner()
+    run.optimizer = opt
+    hook = DistOptimizerHook(update_interval=3, grad_clip=dict(max_norm=40), coalesce=True, bucket_size_mb=-1, use_fp16=True)
+    hook.before_run(run)
+    for it in range(6):
+        run.iter = it
+        run.outputs = dict(loss=Loss(opt, 3.0))
+        hook.after_train_iter(run)
+    micro = [("backward", 1.0, True), ("backward", 1.0, True), ("backward", 1.0, False), ("clip", 40), "step", "zero"]
+    assert opt.log == ["zero"] + micro + micro
