@@ -788,7 +788,7 @@ class _BackboneFn(torch.autograd.Function):
         # patch embedding as a GEMM (conv1: kernel = stride = patch, no bias; vit_clip.py:436)
         Kp = frozen["conv"].shape[1]
         A = _empty((BT * G * G, Kp), BF16, dev)
-        ops.patchify(imgs, A, B, T, Hh, Ww, p, Kp, model._norm_mean, model._norm_std)
+        ops.patchify(imgs, A, B, T, Hh, Ww, p, Kp, *model._norm_now)
         tok = _empty((BT * G * G, D), BF16, dev)
         ops.gemm(A, frozen["conv"], ops.EPI_BF16, tok)
         del A
@@ -957,7 +957,8 @@ class ViT_CLIP(nn.Module):
         self.transformer = Transformer(num_frames, width, layers, heads, scale=adapter_scale, drop_path=drop_path_rate)
         self.ln_post = LayerNorm(width)
         self._frozen_cache = None
-        self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py)
+        self._norm_mean = self._norm_std = None     # set by a fused GPUNormalize hook (module_hooks.py) for the NEXT forward only
+        self._norm_now = (None, None)               # what this forward's patch gather applies
         self.grad_in_place = False                  # accumulate straight into param.grad (see _BackboneFn.backward)
         self.grad_ready_hook = None                 # fn(layer, in_place, streams): set by dist.FlatAdamW (overlapped all-reduce)
         self._fp8_cache = None
@@ -1159,6 +1160,12 @@ class ViT_CLIP(nn.Module):
         if x.dtype == torch.float16:
             x = x.float()
         x = x.contiguous()
+        # a fused GPUNormalize pre-hook arms the normalisation for THIS call (it runs before every forward it is registered
+        # for): consumed here, so a removed hook or a caller that normalised the clip itself is not normalised twice
+        self._norm_now = (self._norm_mean, self._norm_std) if x.dtype == torch.uint8 else (None, None)
+        self._norm_mean = self._norm_std = None
+        if x.dtype == torch.uint8 and self._norm_now[0] is None:
+            raise TypeError("uint8 clips need a GPUNormalize module hook on the backbone (module_hooks.py:35-87)")
         if self.precision == 'fp32':
             if torch.is_grad_enabled() and any(p.requires_grad for p in self._trainable_list()):
                 raise RuntimeError("precision='fp32' is the forward-only reference-precision mode: call it under "

@@ -288,3 +288,12 @@ def test_uint8_input_with_fused_gpu_normalize(golden_dir):
     assert _relerr(out, ref) < 2e-3, _relerr(out, ref)
     with pytest.raises(AssertionError, match="uint8"):
         model.backbone(u8.float().to(DEV))
+    # the fused normalisation is armed per call by the hook: once the hook is gone, an already-normalised float clip is
+    # NOT normalised again, and a uint8 clip without a hook is refused
+    for h in handles:
+        h.remove()
+    with torch.no_grad():
+        again = model.backbone(O.ref_gpu_normalize(u8, mean, std).to(DEV))
+        assert torch.equal(again, ref)
+        with pytest.raises(TypeError, match="GPUNormalize"):
+            model.backbone(u8.to(DEV))
