@@ -206,6 +206,17 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     }
     AIM_CHECK_ARG(!g.aux_frag, "gemm: aux_frag needs the large-tile kernel (ACT / DACT, batch 1, M >= 1024, N %% 8 == 0, K %% 64 == 0)");
     AIM_CHECK_ARG(!g.xrow, "gemm: `xrow` is only supported by the one-tile-per-item EXPSUM path");
+    // very few rows (the class-token chain at one sample x 3 views per call: B*T = 96 rows): the latency-oriented 64 x 64
+    // kernel (gemm_small.hip).  Measured (tools/inf_batch_probe.py, interleaved): ViT-L/14 3-view inference 179 -> 210 views/s
+    // (fp8), the main stream's wait for the chain 2.7 -> 0.75 ms per step; at B*T = 512 (training, 64 clips) the chain is not on
+    // the critical path and the kernel is neutral (1 274 vs 1 277 clips/s), so this file's 128 x 128 kernel keeps those.
+    // AIM_GEMM_SMALL=rows moves the threshold (0: never).
+    static const int small_rows = [] { const char* e = getenv("AIM_GEMM_SMALL"); return e ? atoi(e) : 256; }();
+    if (g.M <= small_rows && epi != EPI_EXPSUM && (g.K % 64) == 0) {
+        if (epi == EPI_ACT) AIM_CHECK_ARG(g.out2 && (g.ldo2 % 4) == 0, "gemm: ACT epilogue needs out2");
+        if (epi == EPI_DACT) AIM_CHECK_ARG(g.aux && (g.ldaux % 4) == 0, "gemm: DACT epilogue needs aux");
+        return aim_gemm_small_launch(g, epi, batch, st);
+    }
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(g, batch, st);
         case EPI_ACT:
