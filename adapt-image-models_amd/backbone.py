@@ -969,12 +969,14 @@ class ViT_CLIP(nn.Module):
         self.inference_precision = 'fp8' if os.environ.get("AIM_INFER_FP8", "0") == "1" else 'bf16'
         self._cast_table = None
         # 'bf16': the product (bf16 MFMA operands, hand-written backward).  'fp32': the reference-precision verification
-        # forward (fp32_path.py; no-grad only), held to the reference's own fp32 outputs at 1e-5.
+        # mode (fp32_path.py: forward and the same hand-written backward on fp32 kernels), held to the reference's own fp32
+        # outputs and autograd gradients at 1e-5.
         self.precision = 'bf16'
 
     def set_precision(self, precision: str):
-        """'bf16' (default) | 'fp32': arithmetic of the forward.  fp32 = f32-MFMA kernels with the reference's fp32
-        arithmetic (vit_clip.py:433-458), ~1/16 of the bf16 MFMA rate, forward-only."""
+        """'bf16' (default) | 'fp32': arithmetic of the forward and backward.  fp32 = f32-MFMA kernels with the reference's
+        fp32 arithmetic (vit_clip.py:433-458), ~1/16 of the bf16 MFMA rate: the verification mode (one stream, plain
+        autograd outputs -- no flat-buffer accumulation, no overlapped all-reduce, no activation checkpointing)."""
         if precision not in ('bf16', 'fp32'):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.precision = precision
@@ -1167,10 +1169,9 @@ class ViT_CLIP(nn.Module):
         if x.dtype == torch.uint8 and self._norm_now[0] is None:
             raise TypeError("uint8 clips need a GPUNormalize module hook on the backbone (module_hooks.py:35-87)")
         if self.precision == 'fp32':
+            from .fp32_path import _BackboneFn32, forward_f32
             if torch.is_grad_enabled() and any(p.requires_grad for p in self._trainable_list()):
-                raise RuntimeError("precision='fp32' is the forward-only reference-precision mode: call it under "
-                                   "torch.no_grad() (training runs the bf16 path)")
-            from .fp32_path import forward_f32
+                return _BackboneFn32.apply(self, x, *self._trainable_list()).unsqueeze(-1).unsqueeze(-1)
             with torch.no_grad():
                 return forward_f32(self, x).unsqueeze(-1).unsqueeze(-1)
         y = _BackboneFn.apply(self, torch.is_grad_enabled(), x, *self._trainable_list())     # [B, D, T]

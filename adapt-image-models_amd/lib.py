@@ -86,10 +86,15 @@ SIGNATURES = {
     "aim_cls_attn_fwd_f32": [P, L, P, I, I, I, P],
     "aim_lambda_f32": [P, I, P, P, I, P, P, I, I, I, F, P],
     "aim_patchify_f32": [P, I, P, P, P, I, I, I, I, I, I, P],
-    "aim_embed_ln_f32": [P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "aim_embed_ln_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "aim_attn_bwd_f32_workspace_bytes": [I, I, I],
+    "aim_attn_bwd_f32": [P, P, P, I, I, I, P, L, P],
+    "aim_cls_attn_bwd_f32": [P, L, P, P, I, I, I, P],
+    "aim_wgrad_f32_workspace_bytes": [I, I, I],
+    "aim_wgrad_f32": [P, I, P, I, P, I, I, I, P, P, I, P, L, P],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def load_library():

@@ -509,9 +509,12 @@ class CastTable:
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, bias=None, resid=None, af=None, at=None,
              vec=None, bt=None, ntok: int = 0, act: int = 0, n_split: int = 0, act2: int = 0, ldv: Optional[int] = None,
              batch: int = 1, stride_a: int = 0, stride_w: int = 0, M: Optional[int] = None, N: Optional[int] = None,
-             K: Optional[int] = None, lda: Optional[int] = None, ldw: Optional[int] = None, ldo: Optional[int] = None):
-    """``out(f32) = epilogue(a @ w.T)`` with fp32 operands on the f32 MFMA; ``epi`` in (EPI_BF16 = linear, EPI_ACT, EPI_F32)."""
-    for n_, t_ in (("a", a), ("w", w), ("out", out), ("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt)):
+             K: Optional[int] = None, lda: Optional[int] = None, ldw: Optional[int] = None, ldo: Optional[int] = None,
+             out2=None, aux=None):
+    """``out(f32) = epilogue(a @ w.T)`` with fp32 operands on the f32 MFMA; ``epi`` in (EPI_BF16 = linear, EPI_ACT, EPI_DACT,
+    EPI_F32).  ``out2`` (EPI_ACT): receives the f32 pre-activation; ``aux`` (EPI_DACT): that pre-activation."""
+    for n_, t_ in (("a", a), ("w", w), ("out", out), ("bias", bias), ("resid", resid), ("af", af), ("at", at), ("vec", vec), ("bt", bt),
+                   ("out2", out2), ("aux", aux)):
         _chk(t_, F32, n_)
     g = GemmArgs()
     g.A, g.W = a.data_ptr(), w.data_ptr()
@@ -529,6 +532,10 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, epi: int, out: torch.Tensor, *, b
     g.out = out.data_ptr()
     g.ldo = (out.stride(-2) if out.dim() >= 2 else g.N) if ldo is None else ldo
     g.act, g.n_split, g.act2, g.scale = act, n_split, act2, 1.0
+    if out2 is not None:
+        g.out2, g.ldo2 = out2.data_ptr(), out2.stride(0)
+    if aux is not None:
+        g.aux, g.ldaux = aux.data_ptr(), aux.stride(0)
     check(load_library().aim_gemm_f32(byref(g), epi, batch, _stream()), "aim_gemm_f32")
     return out
 
@@ -561,8 +568,44 @@ def patchify_f32(imgs, A, B, T, H, W, p, Kp, mean3=None, std3=None):
                                           p, Kp, _stream()), "aim_patchify_f32")
 
 
-def embed_ln_f32(tok, cls, pos, temporal, gamma, beta, x, B, T, N, D, eps=1e-5):
-    for n_, t_ in (("tok", tok), ("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("beta", beta), ("x", x)):
+def embed_ln_f32(tok, cls, pos, temporal, gamma, beta, x, B, T, N, D, eps=1e-5, pre=None, mean=None, rstd=None):
+    """``pre`` / ``mean`` / ``rstd`` (all or none): ln_pre's input rows and statistics, for the backward."""
+    for n_, t_ in (("tok", tok), ("cls", cls), ("pos", pos), ("temporal", temporal), ("gamma", gamma), ("beta", beta), ("x", x),
+                   ("pre", pre), ("mean", mean), ("rstd", rstd)):
         _chk(t_, F32, n_)
     check(load_library().aim_embed_ln_f32(tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), temporal.data_ptr(), gamma.data_ptr(),
-                                          beta.data_ptr(), x.data_ptr(), B, T, N, D, eps, _stream()), "aim_embed_ln_f32")
+                                          beta.data_ptr(), x.data_ptr(), _p(pre), _p(mean), _p(rstd), B, T, N, D, eps, _stream()),
+          "aim_embed_ln_f32")
+
+
+def attn_bwd_f32(qkv, dout, dqkv, BT, N, H):
+    """dqkv [BT*N, 3D] (written) from the fused f32 qkv rows and d(out) [BT*N, D]; probabilities recomputed."""
+    for n_, t_ in (("qkv", qkv), ("dout", dout), ("dqkv", dqkv)):
+        _chk(t_, F32, n_)
+    lib = load_library()
+    nbytes = lib.aim_attn_bwd_f32_workspace_bytes(BT, N, H)
+    ws = torch.empty((nbytes // 4,), dtype=F32, device=qkv.device)
+    check(lib.aim_attn_bwd_f32(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), BT, N, H, ws.data_ptr(), nbytes, _stream()),
+          "aim_attn_bwd_f32")
+
+
+def cls_attn_bwd_f32(qkv, row_stride: int, dout_cls, dqkv, B, T, H):
+    """d(out_cls) [B*T, D] -> ADDED into the class rows of dqkv (call after ``attn_bwd_f32``)."""
+    for n_, t_ in (("qkv", qkv), ("dout_cls", dout_cls), ("dqkv", dqkv)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_cls_attn_bwd_f32(qkv.data_ptr(), int(row_stride), dout_cls.data_ptr(), dqkv.data_ptr(), B, T, H,
+                                              _stream()), "aim_cls_attn_bwd_f32")
+
+
+def wgrad_f32(g, a, dw, db=None, at=None, ntok: int = 0):
+    """``dw [Nw, Kw] += g.T @ a``; ``db [Nw] += sum_m at[m % ntok] * g[m]`` (fp32; row-strided views allowed)."""
+    for n_, t_ in (("g", g), ("a", a), ("dw", dw), ("db", db), ("at", at)):
+        _chk(t_, F32, n_)
+    M, Nw = g.shape
+    Kw = a.shape[1]
+    assert a.shape[0] == M and tuple(dw.shape) == (Nw, Kw) and dw.is_contiguous() and g.stride(1) == 1 and a.stride(1) == 1
+    lib = load_library()
+    nbytes = lib.aim_wgrad_f32_workspace_bytes(M, Nw, Kw)
+    ws = torch.empty((nbytes // 4,), dtype=F32, device=g.device)
+    check(lib.aim_wgrad_f32(g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), dw.data_ptr(), M, Nw, Kw, _p(db), _p(at), ntok,
+                            ws.data_ptr(), nbytes, _stream()), "aim_wgrad_f32")

@@ -32,7 +32,7 @@ extern "C" {
 
 typedef uint16_t aim_bf16;
 
-#define AIM_ABI_VERSION 4
+#define AIM_ABI_VERSION 5
 
 int aim_version(void);                /* == AIM_ABI_VERSION */
 const char* aim_last_error(void);     /* message of the last failing call on this thread */
@@ -323,15 +323,17 @@ int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* 
                 float* out3, int B, int C, int k2 /* second k of the accuracy pair, 5 */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Reference-precision (fp32) forward path: `ViT_CLIP.set_precision('fp32')`, no-grad forwards only.  The product path
+ * Reference-precision (fp32) path: `ViT_CLIP.set_precision('fp32')`, forward AND backward.  The product path
  * computes on bf16 MFMA operands; these entry points compute the SAME block from fp32 operands with fp32 accumulation
  * (v_mfma_f32_16x16x4_f32: exact f32 products, 1/16 of the bf16 rate), exact erf / exp, probabilities normalised before
  * P V -- the arithmetic of the reference's un-autocast run (vit_clip.py:433-458), so the GPU output is held DIRECTLY to
  * the reference's fixtures at 1e-5 (BASELINE north_star), with no bf16-emulating oracle in between.
  *   gemm_f32       : C = A W^T with A, W, bias, resid, out all f32 (aim_gemm_args with float operands); epilogues
  *                    AIM_EPI_BF16 (read: linear, out(f32) = rs * (acc + bias)), AIM_EPI_ACT (out(f32) = [rs *] act(acc + bias),
- *                    n_split / act2 as above; nothing saved), AIM_EPI_F32; batch > 1 (linear only) writes item z at
- *                    out + z * M * ldo.  K, lda, ldw multiples of 4.  replaces vit_clip.py:93-97,132-138,157,286,436.
+ *                    n_split / act2 as above; out2 != NULL receives the f32 pre-activation acc + bias, ldo2 floats per row),
+ *                    AIM_EPI_DACT (out = [rs *] acc * act'(aux): aux = that f32 pre-activation, ldaux floats per row; exact
+ *                    erf / exp derivative; aux_grad / aux_frag are ignored), AIM_EPI_F32; batch > 1 (linear only) writes
+ *                    item z at out + z * M * ldo.  K, lda, ldw multiples of 4.  replaces vit_clip.py:93-97,132-138,157,286,436.
  *   attn_fwd_f32   : softmax(q k^T / 8) v per (frame, head) on the fused f32 qkv rows [BT*N, 3D]; out [BT*N, D].  :139-156
  *   cls_attn_fwd_f32 : the same over the T class tokens of each clip (sequence T, batch B); qkv rows of the class tokens
  *                    are `row_stride` floats apart (N * 3D in the fused buffer); out [B*T, D].  :220-229
@@ -339,6 +341,19 @@ int aim_ce_topk(const float* score, const int64_t* label, float* dscore, float* 
  *                    cross-attention's single key; lam = cw / (cw + ow) with ow = sum_ij exp(scale s_ij), cw = sum_i
  *                    exp(scale q_i . kx), one shared max shift.  :149-151,184-186,272
  *   patchify_f32 / embed_ln_f32 : aim_patchify / aim_embed_ln with an f32 patch matrix / f32 tokens (in_dtype 0 | 1).  :434-447
+ *                    embed_ln_f32: pre / mean / rstd (all three or none) receive ln_pre's input rows [B*T*N, D] and statistics
+ *                    -- what aim_layernorm_bwd needs for the gradient of the trainable temporal_embedding (:344,446).
+ * Backward (the reference gets it from torch autograd; these follow autograd's formulas: softmax backward
+ * dS = P o (dP - rowsum(P o dP)) then the 1/sqrt(dh) of :147, addmm backward for the Adapter's Linear layers):
+ *   attn_bwd_f32   : dqkv [BT*N, 3D] (all three thirds WRITTEN) from qkv and d(out) [BT*N, D]; probabilities recomputed;
+ *                    workspace of aim_attn_bwd_f32_workspace_bytes (row log-sum-exp and rowsum(P o dP)).  :139-156
+ *   cls_attn_bwd_f32 : d(out_cls) [B*T, D] -> ADDED into the class rows of dqkv (row_stride floats apart), which already
+ *                    hold the spatial attention's share (call after attn_bwd_f32).  :220-229
+ *   wgrad_f32      : dW [Nw, Kw] += sum_m G[m][n] A[m][k]; db [Nw] += sum_m at[m % ntok] G[m][n] (at NULL -> 1; db NULL -> no
+ *                    bias); G [M, ldg], A [M, lda] f32.  M is reduced in chunks whose partial results are summed in chunk
+ *                    order (workspace of aim_wgrad_f32_workspace_bytes; no atomics).  Adapter.D_fc1 / D_fc2, :57-58,62-64
+ * LayerNorm backward, the per-frame sums and the row scaling of the fp32 backward are the f32 forms of aim_layernorm_bwd,
+ * aim_frame_sum and aim_scale_rows above.
  * ------------------------------------------------------------------------------------------ */
 int aim_gemm_f32(const aim_gemm_args* args, int epilogue, int batch, void* stream);
 int aim_attn_fwd_f32(const float* qkv, float* out, int BT, int N, int H, void* stream);
@@ -348,7 +363,16 @@ int aim_lambda_f32(const float* scores, int lds, const float* qkv, const float* 
 int aim_patchify_f32(const void* imgs, int in_dtype, const float* mean3, const float* std3, float* A, int B, int T,
                      int H, int W, int p, int Kp, void* stream);
 int aim_embed_ln_f32(const float* tok, const float* cls, const float* pos, const float* temporal, const float* gamma,
-                     const float* beta, float* x, int B, int T, int N, int D, float eps, void* stream);
+                     const float* beta, float* x, float* pre, float* mean, float* rstd, int B, int T, int N, int D, float eps,
+                     void* stream);
+int64_t aim_attn_bwd_f32_workspace_bytes(int BT, int N, int H);
+int aim_attn_bwd_f32(const float* qkv, const float* dout, float* dqkv, int BT, int N, int H, float* workspace,
+                     int64_t workspace_bytes, void* stream);
+int aim_cls_attn_bwd_f32(const float* qkv, int64_t row_stride, const float* dout_cls, float* dqkv, int B, int T, int H,
+                         void* stream);
+int64_t aim_wgrad_f32_workspace_bytes(int M, int Nw, int Kw);
+int aim_wgrad_f32(const float* G, int ldg, const float* A, int lda, float* dW, int M, int Nw, int Kw, float* db,
+                  const float* at, int ntok, float* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

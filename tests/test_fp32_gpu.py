@@ -164,8 +164,8 @@ def test_fp32_backbone_tiny_vs_reference(golden_dir, T):
     _record(f"fp32_backbone_tiny_T{T}", y_maxrel=e, score_maxrel=e_s)
     assert e <= TOL and e_s <= TOL, (e, e_s)
     assert torch.equal(score.argmax(1).cpu(), z["pred"].long())
-    with pytest.raises(RuntimeError, match="forward-only"):
-        m(z["imgs"].to(DEV))                      # grad mode on: the verification mode refuses to pose as trainable
+    yg = m(z["imgs"].to(DEV))                     # grad mode on: the same numbers, now with the fp32 backward attached
+    assert yg.requires_grad and torch.equal(yg.detach(), y)      # (gradients: tests/test_fp32_bwd_gpu.py)
 
 
 @pytest.mark.parametrize("T", [2, 4])
