@@ -1040,9 +1040,17 @@ class ViT_CLIP(nn.Module):
         return {'relative_position_bias_table', 'temporal_position_bias_table'}
 
     # ---- operand staging ------------------------------------------------------------------------
+    def _param_slots(self, root, tag):
+        """(module, name) of every parameter under ``root``, walked once: the per-forward cache keys below read the CURRENT
+        tensors of those slots (a re-assigned parameter is seen) without walking the module tree (1 ms per forward)."""
+        cache = self.__dict__.setdefault("_slot_cache", {})
+        if tag not in cache:
+            cache[tag] = [(m, n) for m in root.modules() for n in m._parameters if m._parameters[n] is not None]
+        return [m._parameters[n] for m, n in cache[tag]]
+
     def _frozen_params(self):
         skip = set(id(p) for p in self._trainable_list())
-        return [p for p in self.parameters() if id(p) not in skip]
+        return [p for p in self._param_slots(self, "all") if id(p) not in skip]
 
     def _frozen_operands(self):
         """bf16 copies of the frozen weights; rebuilt only when a frozen tensor changed or moved."""
@@ -1074,7 +1082,7 @@ class ViT_CLIP(nn.Module):
     def _fp8_operands(self):
         """Per-block fp8 operands; rebuilt only when any block weight changed or moved."""
         # (FlatAdamW updates the adapters through raw pointers -- no tensor version changes -- and bumps `weights_epoch`)
-        key = tuple((p.data_ptr(), p._version) for p in self.transformer.parameters()) + (self.weights_epoch,)
+        key = tuple((p.data_ptr(), p._version) for p in self._param_slots(self.transformer, "blocks")) + (self.weights_epoch,)
         if self._fp8_cache is None or self._fp8_cache[0] != key:
             self._fp8_cache = (key, [_Frozen8(b) for b in self.transformer.resblocks])
         return self._fp8_cache[1]

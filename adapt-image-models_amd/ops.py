@@ -18,7 +18,15 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The raw hipStream_t of torch's current stream on the current device.  (`torch.cuda.current_stream()` builds a Stream
+    object behind several Python-level device lookups: 8 us a call, 5 ms per forward at one sample x 3 views of ViT-L/14.)"""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
