@@ -10,6 +10,7 @@
 //   aim_gemm_f32        q/k/v, out_proj, c_fc / c_proj, Adapter.D_fc1 / D_fc2, conv1-as-GEMM (:93-97,132-138,157,436)
 //   aim_attn_fwd_f32    spatial attention per (frame, head) (:139-156)
 //   aim_cls_attn_fwd_f32  temporal attention over the T class tokens of a clip (:220-229)
+//   aim_tattn_fwd_f32     temporal attention over the T frames of every token (stock AIM, vitclip_aim.py:199-204)
 //   aim_lambda_f32      lamda = cw / (cw + ow) from the head-summed logits (:149-151,184-186,272)
 //   aim_patchify_f32, aim_embed_ln_f32   (:434-447)
 // and the BACKWARD of the same steps (the reference gets it from torch autograd), so that the hand-written backward's
@@ -17,7 +18,7 @@
 //   aim_gemm_f32(AIM_EPI_DACT)   dgrad x activation derivative (exact erf / exp) from the saved fp32 pre-activation
 //   aim_attn_bwd_f32             dq / dk / dv of the spatial attention, probabilities recomputed (softmax backward as
 //                                autograd writes it: dS = P o (dP - rowsum(P o dP)), then the 1/sqrt(dh))
-//   aim_cls_attn_bwd_f32         the same over the T class tokens of a clip, accumulated into the class rows of d(qkv)
+//   aim_cls_attn_bwd_f32 / aim_tattn_bwd_f32   the same over sequences of T rows, ACCUMULATED into their rows of d(qkv)
 //   aim_wgrad_f32                adapter weight / bias gradients, fixed summation order (chunk partials + finish)
 #include "aim_common.h"
 #include "aim_kernels_internal.h"
@@ -205,18 +206,23 @@ __global__ __launch_bounds__(512) void attn_f32_kernel(const float* __restrict__
     }
 }
 
-// ---- temporal attention over the T class tokens of a clip: one wave per (clip, head), lane = head dimension -----------
-__global__ __launch_bounds__(64) void cls_attn_f32_kernel(const float* __restrict__ qkv, long long row_stride, float* __restrict__ out,
-                                                          int T, int H) {
+// ---- attention over sequences of T rows (the T class tokens of a clip, :220-229; the T frames of EVERY token in the stock
+// AIM block, vitclip_aim.py:199-204): one wave per (clip, sequence, head), lane = head dimension.  Sequence `n` of clip `b`
+// starts at b * clip + n * seq floats of qkv and its rows are `row` floats apart (out: oclip / oseq / orow).
+struct SeqLayout { long long clip, seq, row, oclip, oseq, orow; int nper; };
+__global__ __launch_bounds__(64) void seq_attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, SeqLayout L, int T,
+                                                          int H) {
     const int D = H * 64, lane = threadIdx.x;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const float* base = qkv + (long long)b * T * row_stride + h * 64 + lane;
+    const int h = blockIdx.x % H, sq = blockIdx.x / H;
+    const int b = sq / L.nper, n = sq - b * L.nper;
+    const float* base = qkv + b * L.clip + n * L.seq + h * 64 + lane;
+    float* ob = out + b * L.oclip + n * L.oseq + h * 64 + lane;
     for (int tq = 0; tq < T; ++tq) {
-        const float qv = base[(long long)tq * row_stride];
+        const float qv = base[tq * L.row];
         float s[32];
         float mx = -INFINITY;
         for (int tk = 0; tk < T; ++tk) {
-            s[tk] = wave_sum(qv * base[(long long)tk * row_stride + D]) * 0.125f;
+            s[tk] = wave_sum(qv * base[tk * L.row + D]) * 0.125f;
             mx = fmaxf(mx, s[tk]);
         }
         float sum = 0.f;
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(64) void cls_attn_f32_kernel(const float* __restric
             sum += s[tk];
         }
         float o = 0.f;
-        for (int tk = 0; tk < T; ++tk) o = fmaf(s[tk] / sum, base[(long long)tk * row_stride + 2 * D], o);
-        out[((long long)b * T + tq) * D + h * 64 + lane] = o;
+        for (int tk = 0; tk < T; ++tk) o = fmaf(s[tk] / sum, base[tk * L.row + 2 * D], o);
+        ob[tq * L.orow] = o;
     }
 }
 
@@ -495,23 +501,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_f32_kernel(const float* __re
     }
 }
 
-// ---- temporal attention over the class tokens, backward: one wave per (clip, head), lane = head dimension --------------
-// ACCUMULATES into the class rows of d(qkv) (rows b T + t at `row_stride`): those rows already hold the spatial attention's
-// share.  The wave is the only writer of its 64 columns of those rows.
-__global__ __launch_bounds__(64) void cls_attn_bwd_f32_kernel(const float* __restrict__ qkv, long long row_stride,
-                                                              const float* __restrict__ dout, float* __restrict__ dqkv, int T, int H) {
+// ---- the same, backward: one wave per (clip, sequence, head).  ACCUMULATES into the sequence's rows of d(qkv) (for the class
+// tokens those rows already hold the spatial attention's share); the wave is the only writer of its 64 columns of those rows.
+__global__ __launch_bounds__(64) void seq_attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              float* __restrict__ dqkv, SeqLayout L, int T, int H) {
     const int D = H * 64, lane = threadIdx.x;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const float* base = qkv + (long long)b * T * row_stride + h * 64 + lane;
-    float* dbase = dqkv + (long long)b * T * row_stride + h * 64 + lane;
+    const int h = blockIdx.x % H, sq = blockIdx.x / H;
+    const int b = sq / L.nper, n = sq - b * L.nper;
+    const long long off = b * L.clip + n * L.seq + h * 64 + lane;
+    const float* base = qkv + off;
+    float* dbase = dqkv + off;
+    const float* dob = dout + b * L.oclip + n * L.oseq + h * 64 + lane;
     for (int tq = 0; tq < T; ++tq) {
-        const float qv = base[(long long)tq * row_stride];
-        const float dov = dout[((long long)b * T + tq) * D + h * 64 + lane];
+        const float qv = base[tq * L.row];
+        const float dov = dob[tq * L.orow];
         float s[32], dp[32];
         float mx = -INFINITY;
         for (int tk = 0; tk < T; ++tk) {
-            s[tk] = wave_sum(qv * base[(long long)tk * row_stride + D]) * 0.125f;
-            dp[tk] = wave_sum(dov * base[(long long)tk * row_stride + 2 * D]);
+            s[tk] = wave_sum(qv * base[tk * L.row + D]) * 0.125f;
+            dp[tk] = wave_sum(dov * base[tk * L.row + 2 * D]);
             mx = fmaxf(mx, s[tk]);
         }
         float sum = 0.f;
@@ -527,11 +535,11 @@ __global__ __launch_bounds__(64) void cls_attn_bwd_f32_kernel(const float* __res
         float dq = 0.f;
         for (int tk = 0; tk < T; ++tk) {
             const float ds = s[tk] * (dp[tk] - del) * 0.125f;
-            dq = fmaf(ds, base[(long long)tk * row_stride + D], dq);
-            dbase[(long long)tk * row_stride + D] += ds * qv;
-            dbase[(long long)tk * row_stride + 2 * D] += s[tk] * dov;
+            dq = fmaf(ds, base[tk * L.row + D], dq);
+            dbase[tk * L.row + D] += ds * qv;
+            dbase[tk * L.row + 2 * D] += s[tk] * dov;
         }
-        dbase[(long long)tq * row_stride] += dq;
+        dbase[tq * L.row] += dq;
     }
 }
 
@@ -648,8 +656,32 @@ extern "C" int aim_attn_fwd_f32(const float* qkv, float* out, int BT, int N, int
 
 extern "C" int aim_cls_attn_fwd_f32(const float* qkv, int64_t row_stride, float* out_cls, int B, int T, int H, void* stream) {
     AIM_CHECK_ARG(qkv && out_cls && B > 0 && T > 0 && T <= 32 && H > 0, "cls_attn_fwd_f32: unsupported shape B=%d T=%d H=%d (T <= 32)", B, T, H);
-    hipLaunchKernelGGL(cls_attn_f32_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, (long long)row_stride, out_cls, T, H);
+    const long long D = (long long)H * 64;
+    const SeqLayout L{T * (long long)row_stride, 0, (long long)row_stride, T * D, 0, D, 1};
+    hipLaunchKernelGGL(seq_attn_f32_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, out_cls, L, T, H);
     AIM_CHECK_LAUNCH("aim_cls_attn_fwd_f32");
+    return 0;
+}
+
+static SeqLayout tattn_layout(int T, int N, int H) {
+    const long long D = (long long)H * 64;
+    return SeqLayout{T * (long long)N * 3 * D, 3 * D, N * 3 * D, T * (long long)N * D, D, N * D, N};
+}
+
+extern "C" int aim_tattn_fwd_f32(const float* qkv, float* out, int B, int T, int N, int H, void* stream) {
+    AIM_CHECK_ARG(qkv && out && B > 0 && T > 0 && T <= 32 && N > 0 && H > 0, "tattn_fwd_f32: unsupported shape B=%d T=%d N=%d H=%d (T <= 32)",
+                  B, T, N, H);
+    hipLaunchKernelGGL(seq_attn_f32_kernel, dim3(B * N * H), dim3(64), 0, (hipStream_t)stream, qkv, out, tattn_layout(T, N, H), T, H);
+    AIM_CHECK_LAUNCH("aim_tattn_fwd_f32");
+    return 0;
+}
+
+extern "C" int aim_tattn_bwd_f32(const float* qkv, const float* dout, float* dqkv, int B, int T, int N, int H, void* stream) {
+    AIM_CHECK_ARG(qkv && dout && dqkv && B > 0 && T > 0 && T <= 32 && N > 0 && H > 0,
+                  "tattn_bwd_f32: unsupported shape B=%d T=%d N=%d H=%d (T <= 32)", B, T, N, H);
+    hipLaunchKernelGGL(seq_attn_bwd_f32_kernel, dim3(B * N * H), dim3(64), 0, (hipStream_t)stream, qkv, dout, dqkv, tattn_layout(T, N, H),
+                       T, H);
+    AIM_CHECK_LAUNCH("aim_tattn_bwd_f32");
     return 0;
 }
 
@@ -720,8 +752,9 @@ extern "C" int aim_cls_attn_bwd_f32(const float* qkv, int64_t row_stride, const 
                                     void* stream) {
     AIM_CHECK_ARG(qkv && dout_cls && dqkv && B > 0 && T > 0 && T <= 32 && H > 0,
                   "cls_attn_bwd_f32: unsupported shape B=%d T=%d H=%d (T <= 32)", B, T, H);
-    hipLaunchKernelGGL(cls_attn_bwd_f32_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, (long long)row_stride, dout_cls,
-                       dqkv, T, H);
+    const long long D = (long long)H * 64;
+    const SeqLayout L{T * (long long)row_stride, 0, (long long)row_stride, T * D, 0, D, 1};
+    hipLaunchKernelGGL(seq_attn_bwd_f32_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, dout_cls, dqkv, L, T, H);
     AIM_CHECK_LAUNCH("aim_cls_attn_bwd_f32");
     return 0;
 }

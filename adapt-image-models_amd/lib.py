@@ -90,6 +90,8 @@ SIGNATURES = {
     "aim_attn_bwd_f32_workspace_bytes": [I, I, I],
     "aim_attn_bwd_f32": [P, P, P, I, I, I, P, L, P],
     "aim_cls_attn_bwd_f32": [P, L, P, P, I, I, I, P],
+    "aim_tattn_fwd_f32": [P, P, I, I, I, I, P],
+    "aim_tattn_bwd_f32": [P, P, P, I, I, I, I, P],
     "aim_wgrad_f32_workspace_bytes": [I, I, I],
     "aim_wgrad_f32": [P, I, P, I, P, I, I, I, P, P, I, P, L, P],
 }

@@ -605,6 +605,20 @@ def cls_attn_bwd_f32(qkv, row_stride: int, dout_cls, dqkv, B, T, H):
                                               _stream()), "aim_cls_attn_bwd_f32")
 
 
+def tattn_fwd_f32(qkv, out, B, T, N, H):
+    """Stock-AIM temporal attention over the T frames of every token (fp32, frame-major fused qkv rows)."""
+    _chk(qkv, F32, "qkv"); _chk(out, F32, "out")
+    check(load_library().aim_tattn_fwd_f32(qkv.data_ptr(), out.data_ptr(), B, T, N, H, _stream()), "aim_tattn_fwd_f32")
+
+
+def tattn_bwd_f32(qkv, dout, dqkv, B, T, N, H):
+    """... its backward, ADDED into ``dqkv`` [B*T*N, 3D]."""
+    for n_, t_ in (("qkv", qkv), ("dout", dout), ("dqkv", dqkv)):
+        _chk(t_, F32, n_)
+    check(load_library().aim_tattn_bwd_f32(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, T, N, H, _stream()),
+          "aim_tattn_bwd_f32")
+
+
 def wgrad_f32(g, a, dw, db=None, at=None, ntok: int = 0):
     """``dw [Nw, Kw] += g.T @ a``; ``db [Nw] += sum_m at[m % ntok] * g[m]`` (fp32; row-strided views allowed)."""
     for n_, t_ in (("g", g), ("a", a), ("dw", dw), ("db", db), ("at", at)):

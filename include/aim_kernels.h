@@ -370,6 +370,10 @@ int aim_attn_bwd_f32(const float* qkv, const float* dout, float* dqkv, int BT, i
                      int64_t workspace_bytes, void* stream);
 int aim_cls_attn_bwd_f32(const float* qkv, int64_t row_stride, const float* dout_cls, float* dqkv, int B, int T, int H,
                          void* stream);
+/* stock-AIM block (vitclip_aim.py:199-204): attention over the T frames of EVERY token, on the frame-major fused f32 qkv rows
+   [B*T*N, 3D]; out / dout [B*T*N, D]; the backward ADDS into dqkv (zero it first when nothing else wrote it) */
+int aim_tattn_fwd_f32(const float* qkv, float* out, int B, int T, int N, int H, void* stream);
+int aim_tattn_bwd_f32(const float* qkv, const float* dout, float* dqkv, int B, int T, int N, int H, void* stream);
 int64_t aim_wgrad_f32_workspace_bytes(int M, int Nw, int Kw);
 int aim_wgrad_f32(const float* G, int ldg, const float* A, int lda, float* dW, int M, int Nw, int Kw, float* db,
                   const float* at, int ntok, float* workspace, int64_t workspace_bytes, void* stream);

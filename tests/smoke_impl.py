@@ -34,7 +34,15 @@ def run_smoke():
     with torch.no_grad():
         y32 = m.set_precision('fp32')(imgs.to("cuda:0")).cpu()
         ref32 = O.ref_backbone(imgs, {k: v.detach() for k, v in st.items()}, H, T)
-    m.set_precision('bf16')
     e32 = ((y32 - ref32).abs().max() / ref32.abs().max()).item()
     assert e32 <= 1e-5, f"smoke fp32 mismatch: {e32}"
-    print(f"smoke ok: bf16 fwd rel err {rel:.2e}, max err {err:.2e}; fp32 mode max-rel err {e32:.2e}")
+    # ... and its backward (the same hand-written backward on fp32 kernels) against the restatement's autograd, per tensor
+    for p in m.parameters():
+        p.grad = None
+    m(imgs.to("cuda:0")).backward(g.to("cuda:0"))
+    m.set_precision('bf16')
+    st32 = {k: v.detach().clone().requires_grad_(k in names) for k, v in st.items()}
+    g32 = torch.autograd.grad(O.ref_backbone(imgs, st32, H, T), [st32[n] for n in names], g)
+    eg = max(((got[n].grad.cpu() - gr).abs().max() / gr.abs().max()).item() for n, gr in zip(names, g32))
+    assert eg <= 1e-5, f"smoke fp32 gradient mismatch: {eg}"
+    print(f"smoke ok: bf16 fwd rel err {rel:.2e}, max err {err:.2e}; fp32 mode max-rel err {e32:.2e}, gradients {eg:.2e}")
