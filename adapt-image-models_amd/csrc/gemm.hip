@@ -197,6 +197,34 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
                                             (epi != EPI_DACT || (g.ldaux % 8) == 0)));
     if (pick != 128 && batch == 1 && epi != EPI_EXPSUM && g.M >= 1024 && g.N >= 64 && wide_ok) {
         AIM_CHECK_ARG(!g.aux_frag || epi == EPI_ACT || epi == EPI_DACT, "gemm: aux_frag is an ACT / DACT option");
+        AIM_CHECK_ARG(g.row0 == 0, "gemm: row0 != 0 is for launches of fewer than 1024 rows");
+        // A THIN last tile round (ViT-L/14: 2 056 tiles = 8.03 rounds of 256 CUs; every N = 1 024 GEMM of the block) costs the
+        // persistent kernel a whole tile time (tools/tail_probe.py: 60-69 of 975 us for c_proj).  Such a launch is cut in two:
+        // the rows that fill whole rounds, and the last one or two row tiles on the latency-oriented 64 x 64 kernel
+        // (gemm_small.hip: same K order, same epilogue arithmetic -- bit-identical outputs), with row0 carrying the rows'
+        // place in the whole problem for the per-frame / per-token factors.  AIM_GEMM_PEEL=0: never.
+        static const bool peel_on = [] { const char* e = getenv("AIM_GEMM_PEEL"); return !e || atoi(e) != 0; }();
+        if (peel_on && (epi == EPI_BF16 || epi == EPI_F32)) {
+            const int ncu = aim_device_cus();
+            const int cus = ncu - (g.reserve_cus > 0 ? g.reserve_cus : 0) > 8 ? ncu - (g.reserve_cus > 0 ? g.reserve_cus : 0) : 8;
+            const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256;
+            const int tiles = tm * tn, full = tiles / cus, left = tiles - full * cus;
+            const int lrt = (left + tn - 1) / tn;                    // row tiles that hold the left-over tiles
+            if (full >= 2 && left > 0 && lrt <= 2 && left * 8 <= cus && (tm - lrt) * tn <= full * cus) {
+                const int M0 = (tm - lrt) * 256;
+                GemmArgs head = g, tail = g;
+                head.M = M0;
+                const long long osz = epi == EPI_F32 ? 4 : 2;
+                tail.M = g.M - M0;
+                tail.row0 = M0;
+                tail.A = (const aim_bf16*)((const char*)g.A + (long long)M0 * g.lda * 2);
+                tail.out = (char*)g.out + (long long)M0 * g.ldo * osz;
+                if (g.resid) tail.resid = g.resid + (long long)M0 * g.ldr;
+                tail.reserve_cus = 0;
+                if (int rc = aim_gemm256_launch(head, epi, 1, st)) return rc;
+                return aim_gemm_small_launch(tail, epi, 1, st);
+            }
+        }
         return aim_gemm256_launch(g, epi, 1, st);
     }
     if (epi == EPI_EXPSUM && aim_expsum_use256(g.M, g.N) && (g.K % 64) == 0) {
@@ -212,7 +240,7 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     // the critical path and the kernel is neutral (1 274 vs 1 277 clips/s), so this file's 128 x 128 kernel keeps those.
     // AIM_GEMM_SMALL=rows moves the threshold (0: never).
     static const int small_rows = [] { const char* e = getenv("AIM_GEMM_SMALL"); return e ? atoi(e) : 256; }();
-    if (g.M <= small_rows && epi != EPI_EXPSUM && (g.K % 64) == 0) {
+    if ((g.M <= small_rows || g.row0 != 0) && epi != EPI_EXPSUM && (g.K % 64) == 0) {
         if (epi == EPI_ACT) AIM_CHECK_ARG(g.out2 && (g.ldo2 % 4) == 0, "gemm: ACT epilogue needs out2");
         if (epi == EPI_DACT) AIM_CHECK_ARG(g.aux && (g.ldaux % 4) == 0, "gemm: DACT epilogue needs aux");
         return aim_gemm_small_launch(g, epi, batch, st);

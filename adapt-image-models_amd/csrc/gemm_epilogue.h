@@ -19,8 +19,9 @@ __device__ __forceinline__ float col_rs(const GemmArgs& g, int n, float rs) {
 __device__ __forceinline__ RowFactors row_factors(const GemmArgs& g, int m) {
     RowFactors r{1.0f, 0.0f, 0};
     if (g.af || g.at || g.vec) {
-        r.frame = m / g.ntok;
-        const int tok = m - r.frame * g.ntok;
+        const int mg = m + g.row0;              // row of the caller's whole problem (aim_gemm_args.row0: a peeled tail launch)
+        r.frame = mg / g.ntok;
+        const int tok = mg - r.frame * g.ntok;
         if (g.af) r.rs *= g.af[r.frame];
         if (g.at) r.rs *= g.at[tok];
         if (g.vec) r.vs = g.bt ? g.bt[tok] : 1.0f;
@@ -51,9 +52,20 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, in
                                            const FragIn& fin) {
     const float rs = (EPI == EPI_ACT || EPI == EPI_DACT) ? col_rs(g, n, rf.rs) : rf.rs;
     const int act = col_act(g, n);
-    if (g.bias) {
-        const f32x4 b = *(const f32x4*)(g.bias + n);
-        if (EPI == EPI_F32 && g.rs_bias_only) v += rs * b; else v += b;
+    if constexpr (EPI == EPI_F32) {
+        // the SAME expression as the 256 x 256 kernel's residual epilogue (wave_epilogue: v * rs + rs * bias with row factors,
+        // v + bias without), so that the rows a peeled tail launch computes are bit-identical to the whole launch's
+        // (spelled out: t = v * rs; v = fma(rs, b, t) -- the contraction the compiler picks there)
+        const f32x4 b = g.bias ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.af || g.at || g.vec) {
+            const float ms = g.rs_bias_only ? 1.0f : rs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rs, b[e], v[e] * ms);
+        } else {
+            v += b;
+        }
+    } else if (g.bias) {
+        v += *(const f32x4*)(g.bias + n);
     }
     if constexpr (EPI == EPI_BF16) {
         v *= rs;
@@ -78,10 +90,10 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, f32x4 v, int m, in
         *(bf16x4*)((bf16_t*)g.out + (long long)m * g.ldo + n) =
             pack4(rs * v[0] * d[0], rs * v[1] * d[1], rs * v[2] * d[2], rs * v[3] * d[3]);
     } else if constexpr (EPI == EPI_F32) {
-        if (!g.rs_bias_only) v *= rs;
         if (g.vec) {
             const f32x4 w = *(const f32x4*)(g.vec + (long long)rf.frame * g.ldv + n);
-            v += rf.vs * w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(w[e], rf.vs, v[e]);
         }
         v += fin.resid;
         *(f32x4*)((float*)g.out + (long long)m * g.ldo + n) = v;

@@ -30,7 +30,7 @@ class GemmArgs(Structure):
         ("scale", c_float), ("act", c_int32), ("rs_bias_only", c_int32), ("n_split", c_int32), ("act2", c_int32),
         ("xrow", c_void_p), ("ldx", c_int32),
         ("reserve_cus", c_int32), ("probe", c_void_p), ("probe_cap", c_int32),
-        ("wscale", c_void_p), ("aux_grad", c_int32), ("aux_frag", c_int32),
+        ("wscale", c_void_p), ("aux_grad", c_int32), ("aux_frag", c_int32), ("row0", c_int32),
     ]
 
 
@@ -96,7 +96,7 @@ SIGNATURES = {
     "aim_wgrad_f32": [P, I, P, I, P, I, I, I, P, P, I, P, L, P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def load_library():

@@ -32,7 +32,7 @@ extern "C" {
 
 typedef uint16_t aim_bf16;
 
-#define AIM_ABI_VERSION 5
+#define AIM_ABI_VERSION 6
 
 int aim_version(void);                /* == AIM_ABI_VERSION */
 const char* aim_last_error(void);     /* message of the last failing call on this thread */
@@ -113,6 +113,11 @@ typedef struct aim_gemm_args {
        [64 lanes] x 4 bf16 -- each lane's own accumulator elements, so neither epilogue re-tiles it (ldo2 / ldaux are
        ignored; the buffer holds ceil(M/256) * ceil(N/256) * 65536 elements). */
     int32_t aux_frag;
+    /* Row index, in the caller's whole problem, of row 0 of THIS launch's A / out / resid pointers: the row factors are read
+       as af[(row0 + m) / ntok], at[(row0 + m) % ntok] (same for vec / bt).  0 for a whole problem.  The library uses it
+       itself when it peels the thin last tile round of a large launch into a second, low-latency launch (AIM_GEMM_PEEL);
+       the small-tile kernels honour it, the persistent 256 x 256 kernel requires 0. */
+    int32_t row0;
 } aim_gemm_args;
 
 int aim_gemm_bf16(const aim_gemm_args* args, int epilogue, int batch, void* stream);
