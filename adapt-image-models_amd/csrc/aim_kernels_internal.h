@@ -15,6 +15,9 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st);
 int aim_gemm256_launch(const GemmArgs& g, int epi, int nbatch, hipStream_t st);
 int aim_gemm256_fp8_launch(const GemmArgs& g, int epi, hipStream_t st);
 int aim_gemm_small_launch(const GemmArgs& g, int epi, int batch, hipStream_t st);
+int aim_gemm_small_fp8_launch(const GemmArgs& g, int epi, hipStream_t st);
+// rows of a thin last tile round that go to the small-tile kernel (0: no peel); fills M0 = rows of the whole rounds
+int aim_gemm_peel_rows(const GemmArgs& g, int* M0);
 // EXPSUM problems of one 256x256 tile per batch item run on the persistent kernel (8 partial slots per item)
 static inline bool aim_expsum_use256(int M, int N) {
     static const bool on = [] { const char* e = getenv("AIM_EXPSUM_256"); return !e || atoi(e) != 0; }();

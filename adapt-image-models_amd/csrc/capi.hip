@@ -49,6 +49,22 @@ extern "C" int aim_gemm_fp8(const aim_gemm_args* args, int epilogue, void* strea
         AIM_CHECK_ARG(g.resid && (g.ldr % 8) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128), "gemm_fp8: RES16 needs a bf16 residual (ldr %% 8 == 0) and ntok >= 128 with vec");
     if (epilogue == EPI_F32) AIM_CHECK_ARG((g.ldr % 4) == 0 && (g.ldv % 4) == 0 && (!g.vec || g.ntok >= 128), "gemm_fp8: F32 epilogue strides");
     if (g.af || g.at || g.vec) AIM_CHECK_ARG(g.ntok > 0, "gemm_fp8: ntok required with row factors");
+    AIM_CHECK_ARG(g.row0 == 0, "gemm_fp8: row0 is set by the library's own tail launches only");
+    // a thin last tile round goes to the small-tile kernel (gemm.hip, aim_gemm_peel_rows): 12 views x 32 frames of ViT-L/14 are
+    // 385.5 row tiles -- 6.03 rounds for out_proj / c_proj, 18.09 for QKV
+    int M0 = 0;
+    if ((epilogue == EPI_BF16 || epilogue == EPI_RES16) && (g.K % 128) == 0 && (g.N % 4) == 0 && aim_gemm_peel_rows(g, &M0) > 0) {
+        GemmArgs head = g, tail = g;
+        head.M = M0;
+        tail.M = g.M - M0;
+        tail.row0 = M0;
+        tail.A = (const aim_bf16*)((const char*)g.A + (long long)M0 * g.lda);
+        tail.out = (char*)g.out + (long long)M0 * g.ldo * 2;
+        if (g.resid) tail.resid = (const float*)((const char*)g.resid + (long long)M0 * g.ldr * 2);      // (RES16: bf16 rows)
+        tail.reserve_cus = 0;
+        if (int rc = aim_gemm256_fp8_launch(head, epilogue, (hipStream_t)stream)) return rc;
+        return aim_gemm_small_fp8_launch(tail, epilogue, (hipStream_t)stream);
+    }
     return aim_gemm256_fp8_launch(g, epilogue, (hipStream_t)stream);
 }
 

@@ -180,6 +180,22 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
 
 }  // namespace
 
+int aim_gemm_peel_rows(const GemmArgs& g, int* M0) {
+    static const bool peel_on = [] { const char* e = getenv("AIM_GEMM_PEEL"); return !e || atoi(e) != 0; }();
+    if (!peel_on) return 0;
+    const int ncu = aim_device_cus();
+    const int res = g.reserve_cus > 0 ? g.reserve_cus : 0;
+    const int cus = ncu - res > 8 ? ncu - res : 8;
+    const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256;
+    const int tiles = tm * tn, full = tiles / cus, left = tiles - full * cus;
+    const int lrt = (left + tn - 1) / tn;                    // row tiles that hold the left-over tiles
+    if (full >= 2 && left > 0 && lrt <= 2 && left * 8 <= cus && (tm - lrt) * tn <= full * cus) {
+        *M0 = (tm - lrt) * 256;
+        return g.M - *M0;
+    }
+    return 0;
+}
+
 int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
     AIM_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
     AIM_CHECK_ARG((g.K % 8) == 0 && (g.lda % 8) == 0 && (g.ldw % 8) == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", g.K, g.lda, g.ldw);
@@ -203,27 +219,19 @@ int aim_gemm_launch(const GemmArgs& g, int epi, int batch, hipStream_t st) {
         // the rows that fill whole rounds, and the last one or two row tiles on the latency-oriented 64 x 64 kernel
         // (gemm_small.hip: same K order, same epilogue arithmetic -- bit-identical outputs), with row0 carrying the rows'
         // place in the whole problem for the per-frame / per-token factors.  AIM_GEMM_PEEL=0: never.
-        static const bool peel_on = [] { const char* e = getenv("AIM_GEMM_PEEL"); return !e || atoi(e) != 0; }();
-        if (peel_on && (epi == EPI_BF16 || epi == EPI_F32)) {
-            const int ncu = aim_device_cus();
-            const int cus = ncu - (g.reserve_cus > 0 ? g.reserve_cus : 0) > 8 ? ncu - (g.reserve_cus > 0 ? g.reserve_cus : 0) : 8;
-            const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256;
-            const int tiles = tm * tn, full = tiles / cus, left = tiles - full * cus;
-            const int lrt = (left + tn - 1) / tn;                    // row tiles that hold the left-over tiles
-            if (full >= 2 && left > 0 && lrt <= 2 && left * 8 <= cus && (tm - lrt) * tn <= full * cus) {
-                const int M0 = (tm - lrt) * 256;
-                GemmArgs head = g, tail = g;
-                head.M = M0;
-                const long long osz = epi == EPI_F32 ? 4 : 2;
-                tail.M = g.M - M0;
-                tail.row0 = M0;
-                tail.A = (const aim_bf16*)((const char*)g.A + (long long)M0 * g.lda * 2);
-                tail.out = (char*)g.out + (long long)M0 * g.ldo * osz;
-                if (g.resid) tail.resid = g.resid + (long long)M0 * g.ldr;
-                tail.reserve_cus = 0;
-                if (int rc = aim_gemm256_launch(head, epi, 1, st)) return rc;
-                return aim_gemm_small_launch(tail, epi, 1, st);
-            }
+        int M0 = 0;
+        if ((epi == EPI_BF16 || epi == EPI_F32) && aim_gemm_peel_rows(g, &M0) > 0) {
+            GemmArgs head = g, tail = g;
+            head.M = M0;
+            const long long osz = epi == EPI_F32 ? 4 : 2;
+            tail.M = g.M - M0;
+            tail.row0 = M0;
+            tail.A = (const aim_bf16*)((const char*)g.A + (long long)M0 * g.lda * 2);
+            tail.out = (char*)g.out + (long long)M0 * g.ldo * osz;
+            if (g.resid) tail.resid = g.resid + (long long)M0 * g.ldr;
+            tail.reserve_cus = 0;
+            if (int rc = aim_gemm256_launch(head, epi, 1, st)) return rc;
+            return aim_gemm_small_launch(tail, epi, 1, st);
         }
         return aim_gemm256_launch(g, epi, 1, st);
     }

@@ -32,6 +32,14 @@ for tag, N, K, ntok in (("n1024_k1024", 1024, 1024, 257), ("n1024_k4352", 1024, 
     y32 = torch.empty((rows, N), device="cuda")
     ops.gemm(a, w, ops.EPI_F32, y32, bias=bias, resid=resid, af=af, vec=vec, bt=bt, ntok=ntok)
     out[tag + ".bf16"], out[tag + ".f32"], out[tag + ".rows"] = y16.cpu(), y32.cpu(), rows
+    if K %% 128 == 0:        # the fp8 inference GEMMs: wscale + bias, the row factor (BF16) and the bf16 residual update (RES16)
+        a8 = torch.randn((rows, K), device="cuda").to(ops.FP8)
+        w8, sc = ops.quantize_fp8_rows(torch.randn((N, K), device="cuda") * 0.05)
+        z16 = torch.empty((rows, N), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_fp8(a8, w8, sc, ops.EPI_BF16, z16, bias=bias, af=af, ntok=ntok)
+        r16 = torch.empty((rows, N), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_fp8(a8, w8, sc, ops.EPI_RES16, r16, bias=bias, resid=resid.to(torch.bfloat16), af=af, vec=vec, bt=bt, ntok=ntok)
+        out[tag + ".fp8_bf16"], out[tag + ".fp8_res16"] = z16.cpu(), r16.cpu()
 torch.save(out, sys.argv[1])
 ''' % ROOT
 
